@@ -1,0 +1,271 @@
+/*
+ * rt_abi.h -- C ABI of the MI355X path-tracing hot path.
+ *
+ * The reference (jesseyoungmann/raytracing) is a Rust binary crate with no FFI
+ * of its own (src/main.rs:10-20 declares only private modules, there is no
+ * lib.rs / build.rs / extern block).  The seam this library replaces is the
+ * in-process region src/main.rs:67-133: the 8-thread fan-out, the per-thread
+ * BvhNode::new (src/bvh.rs:105-147), the pixel/sample triple loop
+ * (src/main.rs:96-116), color() (src/main.rs:165-209) and the 8-way image sum
+ * (src/main.rs:128-133).  Inputs at that seam are a Camera (src/camera.rs:5-14),
+ * a HitableList (src/hitable.rs:94-97) and nx, ny, ns; the output is nx*ny
+ * linear-radiance RGB values, top row first.
+ *
+ * Everything here is plain-old-data: pointers, sizes, fixed-width scalars.
+ * All functions return RT_OK (0) or a negative error code; the text of the
+ * last error of the calling thread is available from rt_last_error().
+ * The caller owns every host buffer it passes in; the library copies what it
+ * needs during the call and keeps no pointer.
+ */
+#ifndef RT_ABI_H
+#define RT_ABI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RT_OK 0
+#define RT_ERR_INVALID (-1)     /* bad argument or inconsistent scene */
+#define RT_ERR_DEVICE (-2)      /* a HIP call failed */
+#define RT_ERR_UNSUPPORTED (-3) /* valid input this build cannot run */
+#define RT_ERR_NO_SCENE (-4)    /* render/trace before rt_upload_scene */
+
+/* ------------------------------------------------------------------------
+ * Flattened scene.
+ *
+ * Nodes are the BvhNode tree of src/bvh.rs:97-103 in breadth-first order,
+ * root at index 0.  An interior node has left >= 0 and right >= 0 (child
+ * indices).  A leaf has left < 0 and refers to ~left:
+ *   right  > 0 : prims[~left .. ~left+right) tested as a HitableList
+ *                (src/hitable.rs:105-117); right == 1 is a bare primitive.
+ *   right == 0 : objects[~left].
+ * bmin/bmax are the node's Aabb (src/bvh.rs:9-12) rounded to fp32.
+ * ---------------------------------------------------------------------- */
+typedef struct rt_node {
+  float bmin[3];
+  int32_t left;
+  float bmax[3];
+  int32_t right;
+} rt_node; /* 32 bytes */
+
+/* Primitive classes.  Rect parameter order follows the constructors
+ * XYRect::new(x0,x1,y0,y1,k) / XZRect::new(x0,x1,z0,z1,k) /
+ * YZRect::new(y0,y1,z0,z1,k) (src/hitable.rs:151,204,278):
+ * f = {a0, a1, b0, b1, k, 0}.  Sphere (src/hitable.rs:40): f = {cx,cy,cz,r,0,0}.
+ * RT_PRIM_FLIP marks a rect wrapped in FlipNormals (src/hitable.rs:320-361). */
+#define RT_PRIM_SPHERE 0
+#define RT_PRIM_XY_RECT 1
+#define RT_PRIM_XZ_RECT 2
+#define RT_PRIM_YZ_RECT 3
+#define RT_PRIM_TYPE_MASK 0xff
+#define RT_PRIM_FLIP 0x100
+
+typedef struct rt_prim {
+  int32_t type;     /* RT_PRIM_* | optional RT_PRIM_FLIP */
+  int32_t material; /* index into materials */
+  float f[6];
+} rt_prim; /* 32 bytes */
+
+/* An object is what the reference nests as
+ *   Translate::new(RotateY::new(inner, angle), offset)
+ * (src/hitable.rs:433,465; either wrapper may be absent) around
+ *   RT_OBJ_LIST  : prims[first .. first+count) as a HitableList (a Cuboid,
+ *                  src/hitable.rs:380-424, is its 6 rects in source order);
+ *   RT_OBJ_BVH   : the sub-tree rooted at nodes[first] (a BvhNode used as a
+ *                  child hitable); its leaves must be prim leaves;
+ *   RT_OBJ_MEDIUM: ConstantMedium (src/hitable.rs:542-604, commented out in
+ *                  the reference) whose boundary is prims[first..first+count)
+ *                  under the same optional rotate/translate. */
+#define RT_OBJ_LIST 0
+#define RT_OBJ_BVH 1
+#define RT_OBJ_MEDIUM 2
+#define RT_XFORM_ROTATE_Y 1
+#define RT_XFORM_TRANSLATE 2
+
+typedef struct rt_object {
+  int32_t kind;  /* RT_OBJ_* */
+  int32_t first; /* first prim, or root node for RT_OBJ_BVH */
+  int32_t count; /* prim count (LIST / MEDIUM) */
+  int32_t xform; /* RT_XFORM_* bits */
+  float sin_theta, cos_theta; /* RotateY (src/hitable.rs:466-469) */
+  float offset[3];            /* Translate */
+  float density;              /* medium */
+  int32_t material;           /* medium phase function (Isotropic) */
+  int32_t medium_index;       /* ordinal among media: selects the RNG stream */
+} rt_object; /* 48 bytes */
+
+/* Material enum of src/material.rs:11-17 (live: Lambertian, DiffuseLight;
+ * Metal :85-113, Dielectric :115-160, Isotropic :206-223 are commented out
+ * there and are restated from that text). */
+#define RT_MAT_LAMBERTIAN 0
+#define RT_MAT_DIFFUSE_LIGHT 1
+#define RT_MAT_METAL 2
+#define RT_MAT_DIELECTRIC 3
+#define RT_MAT_ISOTROPIC 4
+
+typedef struct rt_material {
+  int32_t type;    /* RT_MAT_* */
+  int32_t texture; /* albedo / emit texture (Lambertian, DiffuseLight, Isotropic) */
+  float albedo[3]; /* Metal */
+  float fuzz;      /* Metal, already clamped to <= 1 (src/material.rs:96) */
+  float ref_idx;   /* Dielectric */
+  int32_t pad;
+} rt_material; /* 32 bytes */
+
+/* Texture enum of src/texture.rs:5-17. */
+#define RT_TEX_CONSTANT 0
+#define RT_TEX_CHECKER 1
+#define RT_TEX_NOISE 2
+
+typedef struct rt_texture {
+  int32_t type;   /* RT_TEX_* */
+  float color[3]; /* constant */
+  int32_t odd;    /* checker: texture indices */
+  int32_t even;
+  float scale;    /* noise */
+  int32_t perlin; /* noise: index into perlins */
+} rt_texture; /* 32 bytes */
+
+/* Perlin tables (src/perlin.rs:6-11).  The tables cross the boundary instead
+ * of being regenerated so both sides evaluate identical noise. */
+typedef struct rt_perlin {
+  float ranvec[256][3];
+  int32_t perm_x[256];
+  int32_t perm_y[256];
+  int32_t perm_z[256];
+} rt_perlin;
+
+/* Light shapes for HitablePDF (src/pdf.rs:33-50).  Only XZRect overrides
+ * pdf_value/random in the reference (src/hitable.rs:245-264); color() builds
+ * XZRect(213,343,227,332,554) inline (src/main.rs:177-178).
+ * f = {x0, x1, z0, z1, k, 0}.  Zero lights means CosinePDF alone. */
+#define RT_LIGHT_XZ_RECT 0
+
+typedef struct rt_light {
+  int32_t type;
+  int32_t pad;
+  float f[6];
+} rt_light; /* 32 bytes */
+
+typedef struct rt_scene {
+  const rt_node* nodes;
+  int32_t n_nodes; /* node 0 is the root of the world BVH */
+  const rt_prim* prims;
+  int32_t n_prims;
+  const rt_object* objects;
+  int32_t n_objects;
+  const rt_material* materials;
+  int32_t n_materials;
+  const rt_texture* textures;
+  int32_t n_textures;
+  const rt_perlin* perlins;
+  int32_t n_perlins;
+  const rt_light* lights;
+  int32_t n_lights; /* 0 or 1 */
+} rt_scene;
+
+/* Camera (src/camera.rs:5-14) in f64 exactly as Camera::new computes it;
+ * the device rounds to fp32 on upload. */
+typedef struct rt_camera {
+  double origin[3];
+  double lower_left_corner[3];
+  double horizontal[3];
+  double vertical[3];
+  double u[3];
+  double v[3];
+  double w[3];
+  double lens_radius;
+} rt_camera;
+
+/* Camera::new(lookfrom, lookat, vup, vfov_deg, aspect, aperture, focus_dist),
+ * src/camera.rs:17-51. */
+int rt_camera_init(rt_camera* out, const double lookfrom[3], const double lookat[3],
+                   const double vup[3], double vfov_deg, double aspect, double aperture,
+                   double focus_dist);
+
+#define RT_SKY_BLACK 0    /* SKYBOX_COLOR = 0, src/main.rs:32,208 */
+#define RT_SKY_GRADIENT 1 /* the commented-out gradient, src/main.rs:203-205 */
+
+typedef struct rt_render_params {
+  int32_t nx, ny;       /* image size; v is measured from the bottom row (src/main.rs:103) */
+  int32_t spp;          /* samples per pixel rendered by THIS call */
+  int32_t sample_begin; /* index of the first of them (sample-range sharding) */
+  int32_t max_depth;    /* 50 in the reference (src/main.rs:173) */
+  int32_t sky;          /* RT_SKY_* */
+  float t_min;          /* 0.001 in the reference (src/main.rs:166) */
+  int32_t shard_index;  /* pixel-tile sharding: this call renders only the     */
+  int32_t shard_count;  /* 64x64 tiles t with t % shard_count == shard_index   */
+  uint64_t seed;        /* Philox key */
+} rt_render_params;
+
+/* Random numbers.  The reference draws everything from rand::thread_rng()
+ * (OS seeded, not replayable).  This ABI fixes a counter-based stream instead:
+ * Philox4x32-10 with key (seed low word, seed high word) and counter
+ *   (pixel, sample, slot, sub),   pixel = j*nx + i with j counted from the bottom row.
+ * slot 0 is the camera sample: words 0,1 jitter u,v (src/main.rs:102-103), words
+ * 2,3 the lens-disk candidate of attempt `sub` (src/camera.rs:65-75).
+ * slot 1+depth is the path vertex at that depth: sub 0 word 0 top bit is the
+ * MixturePDF coin (src/pdf.rs:70), words 1,2 the two draws of whichever
+ * generator it picks (src/hitable.rs:259-261 or src/main.rs:241-242), word 3
+ * the Dielectric reflect draw (src/material.rs:152); sub 1+m word 0 is the
+ * ConstantMedium draw of medium m (src/hitable.rs:582); sub 256+a words 0..2
+ * are attempt a of random_in_unit_sphere (src/main.rs:211-221).
+ * A 32-bit word x becomes a uniform in [0,1) as (x >> 8) * 2^-24. */
+
+typedef struct rt_stats {
+  uint64_t paths;          /* camera samples (src/main.rs:101-110) */
+  uint64_t rays;           /* closest-hit queries (src/main.rs:166) */
+  uint64_t hits;           /* of which found a surface (HitRecord built) */
+  uint64_t node_tests;     /* Aabb::hit evaluations (src/bvh.rs:46-61) */
+  uint64_t rect_tests;     /* XY/XZ/YZRect::hit evaluations */
+  uint64_t sphere_tests;   /* Sphere::hit evaluations */
+  uint64_t instance_ops;   /* rays moved into an object's frame */
+  uint64_t shade_events;   /* scattering vertices (mixture sample + both pdf values) */
+  uint64_t light_tests;    /* XZRect::pdf_value rect tests (src/hitable.rs:246) */
+  double kernel_ms;        /* device time of the render kernel */
+} rt_stats;
+
+typedef struct rt_ctx rt_ctx;
+
+const char* rt_last_error(void);
+
+/* One context per (host thread, device).  Not thread-safe. */
+int rt_create(int device_id, rt_ctx** out);
+int rt_destroy(rt_ctx* ctx);
+
+/* Validates and copies the scene to the device (replaces any previous one). */
+int rt_upload_scene(rt_ctx* ctx, const rt_scene* scene);
+
+/* Replaces main.rs:67-133.  Writes per-pixel SUMS (not means) of de_nan'ed
+ * sample radiance, nx*ny*3 floats, top row first, x ascending (main.rs:96-97,
+ * 114).  out_sumsq (optional) receives per-channel sums of squared samples.
+ * stats (optional) selects the event-counting build of the kernel.  Blocking. */
+int rt_render(rt_ctx* ctx, const rt_camera* cam, const rt_render_params* params,
+              float* out_sum_rgb, float* out_sumsq_rgb_or_null, rt_stats* stats_or_null);
+
+/* Same computation with device-resident outputs, enqueued on `hip_stream`
+ * (a hipStream_t passed as void*; NULL is the default stream).  The buffers are
+ * overwritten, not accumulated.  Returns after enqueueing. */
+int rt_render_device(rt_ctx* ctx, const rt_camera* cam, const rt_render_params* params,
+                     float* d_sum_rgb, float* d_sumsq_rgb_or_null, void* hip_stream);
+
+/* Nearest-hit query on a batch of rays: the world.hit(r, t_min, t_max) of
+ * src/main.rs:166 without any random numbers (media are skipped).  o and d are
+ * n*3 floats.  prim_id[i] is the index into prims of the primitive hit, or -1;
+ * t[i] its ray parameter.  normal and p (n*3 floats each) are optional. */
+int rt_trace_closest(rt_ctx* ctx, const float* o, const float* d, size_t n, float t_min,
+                     float t_max, int32_t* prim_id, float* t, float* normal_or_null,
+                     float* p_or_null);
+
+/* main.rs:136-155: divide the sums by spp_total, sqrt, clamp high to 1,
+ * (255.99*c) truncated to u8.  sum_rgb and rgb8 are host buffers. */
+int rt_tonemap(rt_ctx* ctx, const float* sum_rgb, int32_t nx, int32_t ny, int32_t spp_total,
+               uint8_t* rgb8);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT_ABI_H */

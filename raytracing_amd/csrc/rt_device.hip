@@ -1,0 +1,991 @@
+// rt_device.hip -- gfx950 kernels and the rt_* entry points of include/rt_abi.h.
+//
+// Two kernels:
+//   trace_kernel  : nearest hit for a batch of rays (the world.hit of main.rs:166).
+//   render_kernel : the whole sample loop of main.rs:96-116 with color()
+//                   (main.rs:165-209) unrolled into an iterative path loop.
+//
+// Execution model.  One wave64 owns an 8x8 pixel tile and the pool of
+// 64*spp (pixel, sample) items of that tile.  Every trip of the path loop each
+// lane advances its path by one vertex; lanes whose path ended are found with a
+// ballot, ranked with mbcnt and refilled from the head of the pool, so the wave
+// stays full until the pool is empty.  Radiance goes to per-tile accumulators in
+// LDS (ds_add_f32) and is written to HBM once, at the end.
+//
+// Traversal.  For the scene sizes this kernel is built for, 64 incoherent rays
+// visit nearly every node between them, so the wave walks the tree in
+// depth-first order with a wave-uniform node index: node and primitive data
+// arrive through scalar loads into SGPRs, there is no per-lane stack, and each
+// lane only keeps the index of the next node it wants (`lane_next`); a lane whose
+// box test fails sets it to the node's skip link.  Leaves are met in the
+// reference's left-to-right order, so BvhNode::hit's "right wins ties" rule
+// (bvh.rs:212-217) becomes "a later hit replaces the best unless best < t".
+//
+// Arithmetic is fp32.  This file is compiled with -ffp-contract=off; every
+// fused multiply-add is written as fmaf() so that the CPU oracle's fp32 "fused"
+// mode can repeat the intersection arithmetic bit for bit.  Divisions and
+// square roots are the correctly rounded ones.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/rt_abi.h"
+#include "rt_internal.hpp"
+
+namespace {
+
+// ---------------------------------------------------------------------------
+// Device-side scene
+// ---------------------------------------------------------------------------
+enum { SCAN_INTERIOR = 0, SCAN_PRIMS = 1, SCAN_OBJECT = 2 };
+
+// One node of the depth-first ("scan") layout.  Children of an interior node
+// follow it immediately; `skip` is the index of the first node after its subtree.
+struct ScanNode {
+  float bmin[3];
+  int skip;
+  float bmax[3];
+  int kind;
+  int a;  // SCAN_PRIMS: first prim      SCAN_OBJECT: object index
+  int b;  // SCAN_PRIMS: prim count
+  int pad0, pad1;
+};
+
+struct DevScene {
+  const ScanNode* scan;
+  const rt_prim* prims;
+  const rt_object* objects;
+  const rt_material* materials;
+  const rt_texture* textures;
+  const rt_perlin* perlins;
+  int n_scan, n_prims, n_objects, n_lights;
+  rt_light light;
+};
+
+struct DevCamera {
+  float origin[3], llc[3], horizontal[3], vertical[3], u[3], v[3];
+  float lens_radius;
+};
+
+struct F3 {
+  float x, y, z;
+};
+__device__ __forceinline__ F3 f3(float x, float y, float z) { F3 r; r.x = x; r.y = y; r.z = z; return r; }
+__device__ __forceinline__ F3 operator+(F3 a, F3 b) { return f3(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ F3 operator-(F3 a, F3 b) { return f3(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ F3 operator*(F3 a, float s) { return f3(a.x * s, a.y * s, a.z * s); }
+// z*z' + (y*y' + x*x') with single-rounding multiply-adds (the oracle's fused dot).
+__device__ __forceinline__ float dot3(F3 a, F3 b) { return fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x)); }
+__device__ __forceinline__ F3 cross3(F3 a, F3 b) {  // vec3.rs:180-186
+  return f3(a.y * b.z - a.z * b.y, -(a.x * b.z - a.z * b.x), a.x * b.y - a.y * b.x);
+}
+__device__ __forceinline__ F3 unit3(F3 a) { return a * (1.0f / sqrtf(dot3(a, a))); }  // vec3.rs:188-190
+
+struct RayF {
+  F3 o, d, inv;
+};
+__device__ __forceinline__ RayF make_ray(F3 o, F3 d) {
+  RayF r;
+  r.o = o;
+  r.d = d;
+  r.inv = f3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+  return r;
+}
+
+// Translate::hit (hitable.rs:440) then RotateY::hit (hitable.rs:510-518): the ray
+// in the object's frame.  d.y, and so inv.y, is unchanged.
+__device__ __forceinline__ RayF to_object_frame(const RayF& w, int xform, float sin_t, float cos_t, float ox, float oy, float oz) {
+  RayF r = w;
+  if (xform & RT_XFORM_TRANSLATE) r.o = f3(w.o.x - ox, w.o.y - oy, w.o.z - oz);
+  if (xform & RT_XFORM_ROTATE_Y) {
+    const F3 o = r.o, d = r.d;
+    r.o.x = fmaf(cos_t, o.x, -(sin_t * o.z));
+    r.o.z = fmaf(sin_t, o.x, cos_t * o.z);
+    r.d.x = fmaf(cos_t, d.x, -(sin_t * d.z));
+    r.d.z = fmaf(sin_t, d.x, cos_t * d.z);
+    r.inv.x = 1.0f / r.d.x;
+    r.inv.z = 1.0f / r.d.z;
+  }
+  return r;
+}
+
+struct Counters {
+  unsigned long long rays, hits, node_tests, rect_tests, sphere_tests, instance_ops, shade_events, light_tests, paths;
+};
+
+struct Hit {
+  float t;
+  int prim;  // index into prims, -1 = none
+  int obj;   // object whose frame the hit was found in, -1 = world frame
+};
+
+// Aabb::hit (bvh.rs:46-61) with the reference's comparisons: a NaN slab value
+// leaves the interval unchanged (v_max/v_min return the other operand), a
+// negative reciprocal swaps the pair, an empty or zero-width interval misses.
+// The three per-axis exits of the source collapse into one test because the
+// interval only ever shrinks.  Returns the entry parameter through t_enter.
+__device__ __forceinline__ bool slab_test(const ScanNode& n, const RayF& r, float t_min, float t_max, float& t_enter) {
+  float t0 = (n.bmin[0] - r.o.x) * r.inv.x, t1 = (n.bmax[0] - r.o.x) * r.inv.x;
+  float lo = r.inv.x < 0.0f ? t1 : t0, hi = r.inv.x < 0.0f ? t0 : t1;
+  t_min = fmaxf(lo, t_min);
+  t_max = fminf(hi, t_max);
+  t0 = (n.bmin[1] - r.o.y) * r.inv.y; t1 = (n.bmax[1] - r.o.y) * r.inv.y;
+  lo = r.inv.y < 0.0f ? t1 : t0; hi = r.inv.y < 0.0f ? t0 : t1;
+  t_min = fmaxf(lo, t_min);
+  t_max = fminf(hi, t_max);
+  t0 = (n.bmin[2] - r.o.z) * r.inv.z; t1 = (n.bmax[2] - r.o.z) * r.inv.z;
+  lo = r.inv.z < 0.0f ? t1 : t0; hi = r.inv.z < 0.0f ? t0 : t1;
+  t_min = fmaxf(lo, t_min);
+  t_max = fminf(hi, t_max);
+  t_enter = t_min;
+  return !(t_max <= t_min);
+}
+
+// XYRect/XZRect/YZRect::hit (hitable.rs:163-173 and twins).  C is the fixed
+// axis, A and B the in-plane axes in constructor order.  The source's rejects
+// are written as negated comparisons so a NaN passes them exactly as it does
+// there.  t = (k - o[C]) * (1/d[C]) replaces the source's division.
+template <int C, int A, int B>
+__device__ __forceinline__ bool rect_test(const rt_prim& q, const RayF& r, float t0, float t1, float& t_out) {
+  const float oc = C == 0 ? r.o.x : (C == 1 ? r.o.y : r.o.z);
+  const float ic = C == 0 ? r.inv.x : (C == 1 ? r.inv.y : r.inv.z);
+  const float oa = A == 0 ? r.o.x : (A == 1 ? r.o.y : r.o.z);
+  const float da = A == 0 ? r.d.x : (A == 1 ? r.d.y : r.d.z);
+  const float ob = B == 0 ? r.o.x : (B == 1 ? r.o.y : r.o.z);
+  const float db = B == 0 ? r.d.x : (B == 1 ? r.d.y : r.d.z);
+  const float t = (q.f[4] - oc) * ic;
+  const float a = fmaf(t, da, oa);
+  const float b = fmaf(t, db, ob);
+  const bool miss = (t < t0) | (t > t1) | (a < q.f[0]) | (a > q.f[1]) | (b < q.f[2]) | (b > q.f[3]);
+  t_out = t;
+  return !miss;
+}
+
+// Sphere::hit (hitable.rs:50-82): half-b quadratic, nearer root first, strict bounds.
+__device__ __forceinline__ bool sphere_test(const rt_prim& q, const RayF& r, float t_min, float t_max, float& t_out) {
+  const F3 oc = f3(r.o.x - q.f[0], r.o.y - q.f[1], r.o.z - q.f[2]);
+  const float a = dot3(r.d, r.d);
+  const float b = dot3(oc, r.d);
+  const float c = fmaf(-q.f[3], q.f[3], dot3(oc, oc));
+  const float disc = fmaf(b, b, -(a * c));
+  bool hit = false;
+  if (disc > 0.0f) {
+    const float sq = sqrtf(disc);
+    const float inv_a = 1.0f / a;
+    float temp = (-b - sq) * inv_a;
+    if (temp < t_max && temp > t_min) {
+      hit = true;
+    } else {
+      temp = (-b + sq) * inv_a;
+      hit = temp < t_max && temp > t_min;
+    }
+    t_out = temp;
+  }
+  return hit;
+}
+
+// HitableList::hit (hitable.rs:105-117) over prims[first, first+count) with a
+// wave-uniform loop, so the primitive records are scalar loads.  The list's own
+// closest_so_far starts at t_max; the winner then meets the running best under
+// the BVH's tie rule.
+template <bool STATS>
+__device__ __forceinline__ void list_test(const DevScene& S, int first, int count, int obj, bool lane_on, const RayF& r,
+                                          float t_min, float t_max, Hit& best, Counters& cnt) {
+  float loc_t = t_max;
+  int loc_prim = -1;
+  for (int qi = first; qi < first + count; ++qi) {
+    const rt_prim q = S.prims[qi];
+    const int type = q.type & RT_PRIM_TYPE_MASK;
+    float t = 0.0f;
+    bool h = false;
+    if (lane_on) {
+      if (type == RT_PRIM_XY_RECT) h = rect_test<2, 0, 1>(q, r, t_min, loc_t, t);
+      else if (type == RT_PRIM_XZ_RECT) h = rect_test<1, 0, 2>(q, r, t_min, loc_t, t);
+      else if (type == RT_PRIM_YZ_RECT) h = rect_test<0, 1, 2>(q, r, t_min, loc_t, t);
+      else h = sphere_test(q, r, t_min, loc_t, t);
+      if (STATS) {
+        if (type == RT_PRIM_SPHERE) cnt.sphere_tests++;
+        else cnt.rect_tests++;
+      }
+    }
+    if (h) {
+      loc_t = t;
+      loc_prim = qi;
+    }
+  }
+  // bvh.rs:212-217: the earlier hit survives only if it is strictly nearer.
+  if (loc_prim >= 0 && !(best.prim >= 0 && best.t < loc_t)) {
+    best.t = loc_t;
+    best.prim = loc_prim;
+    best.obj = obj;
+  }
+}
+
+__device__ __forceinline__ int wave_min_i32(int v) {
+  for (int off = 32; off > 0; off >>= 1) v = min(v, __shfl_xor(v, off, 64));
+  return v;
+}
+
+// Nearest hit of BvhNode::hit (bvh.rs:197-228) over the scan layout.  Must be
+// called by all 64 lanes of the wave; lanes with active == false take no part.
+// Pruning: a node is also skipped when its entry parameter lies beyond the best
+// hit so far, which cannot change the winner.
+template <bool STATS>
+__device__ __forceinline__ Hit trace_scan(const DevScene& S, bool active, const RayF& w, float t_min, float t_max, Counters& cnt) {
+  Hit best;
+  best.t = t_max;
+  best.prim = -1;
+  best.obj = -1;
+  int lane_next = active ? 0 : 0x7fffffff;
+  RayF loc = w;      // ray in the frame of the sub-tree being walked
+  int inst_end = -1;  // scan index at which that sub-tree ends
+  int inst_obj = -1;
+  int i = 0;
+  const int n_scan = S.n_scan;
+  while (i < n_scan) {
+    i = __builtin_amdgcn_readfirstlane(i);
+    if (i >= inst_end) inst_obj = -1;
+    const bool act = lane_next <= i;
+    if (__ballot(act) == 0ull) {
+      i = wave_min_i32(lane_next);
+      continue;
+    }
+    const ScanNode n = S.scan[i];
+    const bool inside = inst_obj >= 0;
+    bool on = false;
+    if (act) {
+      float t_enter;
+      on = slab_test(n, inside ? loc : w, t_min, t_max, t_enter);
+      if (STATS) cnt.node_tests++;
+      on = on && !(t_enter > best.t);
+      if (!on) lane_next = n.skip;
+    }
+    if (n.kind == SCAN_PRIMS) {
+      if (__ballot(on) != 0ull) list_test<STATS>(S, n.a, n.b, inst_obj, on, inside ? loc : w, t_min, t_max, best, cnt);
+    } else if (n.kind == SCAN_OBJECT) {
+      const rt_object ob = S.objects[n.a];
+      if (ob.kind == RT_OBJ_LIST) {
+        if (__ballot(on) != 0ull) {
+          const RayF r = to_object_frame(w, ob.xform, ob.sin_theta, ob.cos_theta, ob.offset[0], ob.offset[1], ob.offset[2]);
+          if (STATS && on) cnt.instance_ops++;
+          list_test<STATS>(S, ob.first, ob.count, n.a, on, r, t_min, t_max, best, cnt);
+        }
+      } else if (ob.kind == RT_OBJ_BVH) {
+        // The sub-tree's nodes follow inline up to n.skip; lanes that missed the
+        // box already point past it.
+        if (on) loc = to_object_frame(w, ob.xform, ob.sin_theta, ob.cos_theta, ob.offset[0], ob.offset[1], ob.offset[2]);
+        if (STATS && on) cnt.instance_ops++;
+        inst_obj = n.a;
+        inst_end = n.skip;
+      }
+      // RT_OBJ_MEDIUM takes random numbers: the render kernel handles it, a
+      // deterministic query skips it.
+    }
+    ++i;
+  }
+  return best;
+}
+
+struct Surface {
+  F3 p, normal;
+  int material;
+};
+
+// The HitRecord fields color() needs (hitable.rs:175-182, 62-67), carried back
+// to the world frame by RotateY::hit (hitable.rs:521-528) and Translate::hit
+// (hitable.rs:442).
+__device__ __forceinline__ Surface finalize_hit(const DevScene& S, const RayF& w, const Hit& h) {
+  Surface s;
+  const rt_prim q = S.prims[h.prim];
+  RayF r = w;
+  int xform = 0;
+  float sin_t = 0.0f, cos_t = 1.0f, ox = 0.0f, oy = 0.0f, oz = 0.0f;
+  if (h.obj >= 0) {
+    const rt_object ob = S.objects[h.obj];
+    xform = ob.xform; sin_t = ob.sin_theta; cos_t = ob.cos_theta;
+    ox = ob.offset[0]; oy = ob.offset[1]; oz = ob.offset[2];
+    r = to_object_frame(w, xform, sin_t, cos_t, ox, oy, oz);
+  }
+  F3 p = f3(fmaf(h.t, r.d.x, r.o.x), fmaf(h.t, r.d.y, r.o.y), fmaf(h.t, r.d.z, r.o.z));
+  F3 nrm;
+  const int type = q.type & RT_PRIM_TYPE_MASK;
+  if (type == RT_PRIM_SPHERE) {
+    const float inv_r = 1.0f / q.f[3];
+    nrm = f3((p.x - q.f[0]) * inv_r, (p.y - q.f[1]) * inv_r, (p.z - q.f[2]) * inv_r);
+  } else {
+    const float sgn = (q.type & RT_PRIM_FLIP) ? -1.0f : 1.0f;
+    nrm = f3(type == RT_PRIM_YZ_RECT ? sgn : 0.0f, type == RT_PRIM_XZ_RECT ? sgn : 0.0f, type == RT_PRIM_XY_RECT ? sgn : 0.0f);
+  }
+  if (xform & RT_XFORM_ROTATE_Y) {
+    const F3 pl = p, nl = nrm;
+    p.x = fmaf(cos_t, pl.x, sin_t * pl.z);
+    p.z = fmaf(-sin_t, pl.x, cos_t * pl.z);
+    nrm.x = fmaf(cos_t, nl.x, sin_t * nl.z);
+    nrm.z = fmaf(-sin_t, nl.x, cos_t * nl.z);
+  }
+  if (xform & RT_XFORM_TRANSLATE) p = f3(p.x + ox, p.y + oy, p.z + oz);
+  s.p = p;
+  s.normal = nrm;
+  s.material = q.material;
+  return s;
+}
+
+// ---------------------------------------------------------------------------
+// trace_kernel
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) trace_kernel(DevScene S, const float* __restrict__ o, const float* __restrict__ d, size_t n,
+                                                    float t_min, float t_max, int* __restrict__ prim_id, float* __restrict__ t_out,
+                                                    float* __restrict__ normal, float* __restrict__ p_out) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  // Whole waves stay in the loop together: the traversal uses wave-wide operations.
+  const size_t n_round = (n + 63) / 64 * 64;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n_round; idx += stride) {
+    const bool active = idx < n;
+    const size_t at = active ? idx : 0;
+    const RayF w = make_ray(f3(o[3 * at], o[3 * at + 1], o[3 * at + 2]), f3(d[3 * at], d[3 * at + 1], d[3 * at + 2]));
+    Counters cnt;
+    const Hit h = trace_scan<false>(S, active, w, t_min, t_max, cnt);
+    if (active) {
+      prim_id[idx] = h.prim;
+      t_out[idx] = h.prim >= 0 ? h.t : 0.0f;
+      if (normal || p_out) {
+        Surface s;
+        s.p = f3(0, 0, 0);
+        s.normal = f3(0, 0, 0);
+        if (h.prim >= 0) s = finalize_hit(S, w, h);
+        if (normal) { normal[3 * idx] = s.normal.x; normal[3 * idx + 1] = s.normal.y; normal[3 * idx + 2] = s.normal.z; }
+        if (p_out) { p_out[3 * idx] = s.p.x; p_out[3 * idx + 1] = s.p.y; p_out[3 * idx + 2] = s.p.z; }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Philox4x32-10 (Salmon et al., SC'11) and the stream layout of rt_abi.h
+// ---------------------------------------------------------------------------
+struct U4 {
+  unsigned x, y, z, w;
+};
+__device__ __forceinline__ U4 philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1) {
+  const unsigned M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+  for (int round = 0; round < 10; ++round) {
+    const unsigned long long p0 = (unsigned long long)M0 * c0;
+    const unsigned long long p1 = (unsigned long long)M1 * c2;
+    const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0;
+    const unsigned n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1;
+    c1 = (unsigned)p1;
+    c3 = (unsigned)p0;
+    c0 = n0;
+    c2 = n2;
+    k0 += W0;
+    k1 += W1;
+  }
+  U4 r;
+  r.x = c0; r.y = c1; r.z = c2; r.w = c3;
+  return r;
+}
+__device__ __forceinline__ float u01(unsigned x) { return (float)(x >> 8) * (1.0f / 16777216.0f); }
+
+// Texture::value (texture.rs:22-35).  This build evaluates constant textures.
+__device__ __forceinline__ F3 texture_value(const DevScene& S, int tex, F3 p) {
+  const rt_texture t = S.textures[tex];
+  return f3(t.color[0], t.color[1], t.color[2]);
+}
+
+struct RenderArgs {
+  int nx, ny, spp, sample_begin, max_depth, sky;
+  float t_min;
+  int shard_index, shard_count;
+  unsigned key0, key1;
+  int tiles_x, tiles_y;
+};
+
+#define RT_PI_F 3.14159265358979323846f
+
+// ---------------------------------------------------------------------------
+// render_kernel
+// ---------------------------------------------------------------------------
+template <bool STATS, bool SUMSQ>
+__global__ void __launch_bounds__(256) render_kernel(DevScene S, DevCamera cam, RenderArgs A, float* __restrict__ out_sum,
+                                                     float* __restrict__ out_sumsq, unsigned long long* __restrict__ stats) {
+  __shared__ float acc[4][SUMSQ ? 6 : 3][64];
+  const int lane = threadIdx.x & 63;
+  const int wib = threadIdx.x >> 6;
+  const int tile = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wib);
+  if (tile >= A.tiles_x * A.tiles_y) return;
+  const int tx = tile % A.tiles_x, ty = tile / A.tiles_x;
+  if (A.shard_count > 1) {
+    const int big = ((ty * 8) / 64) * ((A.nx + 63) / 64) + (tx * 8) / 64;
+    if (big % A.shard_count != A.shard_index) return;
+  }
+#pragma unroll
+  for (int c = 0; c < (SUMSQ ? 6 : 3); ++c) acc[wib][c][lane] = 0.0f;
+
+  Counters cnt;
+  memset(&cnt, 0, sizeof(cnt));
+
+  const int pool_size = 64 * A.spp;
+  int pool_next = 0;
+
+  // Per-lane path state.
+  bool alive = false;
+  RayF ray = make_ray(f3(0, 0, 0), f3(0, 0, 1));
+  F3 thr = f3(0, 0, 0);   // running product of albedo * scattering_pdf / pdf
+  int depth = 0;
+  int pix = 0;            // pixel within the tile
+  unsigned pixel_id = 0;  // j*nx + i
+  unsigned sample = 0;
+
+  for (;;) {
+    // ---- refill dead lanes from the pool (main.rs:101-107) ----
+    const unsigned long long need = __ballot(!alive);
+    if (need != 0ull && pool_next < pool_size) {
+      const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(need >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)need, 0));
+      const int k = pool_next + rank;
+      pool_next += __popcll(need);
+      if (!alive && k < pool_size) {
+        pix = k & 63;
+        const int s = k >> 6;
+        const int px = tx * 8 + (pix & 7);
+        const int row = ty * 8 + (pix >> 3);  // output row, top first
+        if (px < A.nx && row < A.ny) {
+          const int j = A.ny - 1 - row;
+          pixel_id = (unsigned)(j * A.nx + px);
+          sample = (unsigned)(A.sample_begin + s);
+          U4 w = philox4x32_10(pixel_id, sample, 0u, 0u, A.key0, A.key1);
+          const float u = ((float)px + u01(w.x)) / (float)A.nx;
+          const float v = ((float)j + u01(w.y)) / (float)A.ny;
+          // camera.rs:53-75
+          float rdx = 0.0f, rdy = 0.0f;
+          if (cam.lens_radius != 0.0f) {
+            unsigned attempt = 0;
+            for (;;) {
+              const float dx = 2.0f * u01(w.z) - 1.0f, dy = 2.0f * u01(w.w) - 1.0f;
+              if (fmaf(dy, dy, dx * dx) < 1.0f) { rdx = cam.lens_radius * dx; rdy = cam.lens_radius * dy; break; }
+              ++attempt;
+              w = philox4x32_10(pixel_id, sample, 0u, attempt, A.key0, A.key1);
+            }
+          }
+          const F3 offset = f3(fmaf(cam.v[0], rdy, cam.u[0] * rdx), fmaf(cam.v[1], rdy, cam.u[1] * rdx), fmaf(cam.v[2], rdy, cam.u[2] * rdx));
+          const F3 org = f3(cam.origin[0] + offset.x, cam.origin[1] + offset.y, cam.origin[2] + offset.z);
+          const F3 dir = f3(fmaf(v, cam.vertical[0], fmaf(u, cam.horizontal[0], cam.llc[0])) - cam.origin[0] - offset.x,
+                            fmaf(v, cam.vertical[1], fmaf(u, cam.horizontal[1], cam.llc[1])) - cam.origin[1] - offset.y,
+                            fmaf(v, cam.vertical[2], fmaf(u, cam.horizontal[2], cam.llc[2])) - cam.origin[2] - offset.z);
+          ray = make_ray(org, dir);
+          thr = f3(1.0f, 1.0f, 1.0f);
+          depth = 0;
+          alive = true;
+          if (STATS) cnt.paths++;
+        }
+      }
+    }
+    if (__ballot(alive) == 0ull) {
+      if (pool_next >= pool_size) break;
+      continue;
+    }
+
+    // ---- world.hit(r, 0.001, INFINITY), main.rs:166 ----
+    if (STATS && alive) cnt.rays++;
+    const Hit h = trace_scan<STATS>(S, alive, ray, A.t_min, INFINITY, cnt);
+
+    if (alive) {
+      F3 radiance = f3(0, 0, 0);  // what this vertex adds to the sample, before de_nan
+      bool done = true;
+      if (h.prim < 0) {
+        // main.rs:203-208
+        if (A.sky == RT_SKY_GRADIENT) {
+          const F3 ud = unit3(ray.d);
+          const float t = 0.5f * (ud.y + 1.0f);
+          radiance = f3(thr.x * ((1.0f - t) + t * 0.5f), thr.y * ((1.0f - t) + t * 0.7f), thr.z * ((1.0f - t) + t * 1.0f));
+        }
+      } else {
+        if (STATS) cnt.hits++;
+        const Surface sf = finalize_hit(S, ray, h);
+        const rt_material m = S.materials[sf.material];
+        if (m.type == RT_MAT_DIFFUSE_LIGHT) {
+          // material.rs:197-203: emits towards the side its normal points to; never scatters.
+          if (dot3(sf.normal, ray.d) < 0.0f) {
+            const F3 e = texture_value(S, m.texture, sf.p);
+            radiance = f3(thr.x * e.x, thr.y * e.y, thr.z * e.z);
+          }
+        } else if (depth < A.max_depth) {
+          // Lambertian under MixturePDF(HitablePDF(light), CosinePDF(normal)), main.rs:173-197.
+          if (STATS) cnt.shade_events++;
+          const F3 albedo = texture_value(S, m.texture, sf.p);
+          const U4 w = philox4x32_10(pixel_id, sample, 1u + (unsigned)depth, 0u, A.key0, A.key1);
+          const float xi1 = u01(w.y), xi2 = u01(w.z);
+          // onb.rs:10-21
+          const F3 ww = unit3(sf.normal);
+          const F3 a = fabsf(ww.x) > 0.9f ? f3(0, 1, 0) : f3(1, 0, 0);
+          const F3 vv = unit3(cross3(ww, a));
+          const F3 uu = cross3(ww, vv);
+          F3 dir;
+          const bool pick_light = (S.n_lights > 0) && (w.x >> 31);
+          if (pick_light) {
+            // XZRect::random, hitable.rs:256-264
+            dir = f3(fmaf(xi1, S.light.f[1] - S.light.f[0], S.light.f[0]) - sf.p.x, S.light.f[4] - sf.p.y,
+                     fmaf(xi2, S.light.f[3] - S.light.f[2], S.light.f[2]) - sf.p.z);
+          } else {
+            // random_cosine_direction, main.rs:239-249 (x and y keep the source's factor 2);
+            // v_sin/v_cos take their argument in turns, so phi = 2*pi*r1 is r1 turns.
+            const float z = sqrtf(1.0f - xi2);
+            const float r2s = 2.0f * sqrtf(xi2);
+            const float x = __builtin_amdgcn_cosf(xi1) * r2s;
+            const float y = __builtin_amdgcn_sinf(xi1) * r2s;
+            dir = f3(fmaf(z, ww.x, fmaf(y, vv.x, x * uu.x)), fmaf(z, ww.y, fmaf(y, vv.y, x * uu.y)), fmaf(z, ww.z, fmaf(y, vv.z, x * uu.z)));
+          }
+          const float dlen2 = dot3(dir, dir);
+          const float inv_len = 1.0f / sqrtf(dlen2);
+          // pdf.rs:19-26
+          const float cos_w = dot3(dir, ww) * inv_len;
+          float pdf_val = cos_w > 0.0f ? cos_w * (1.0f / RT_PI_F) : 0.0f;
+          if (S.n_lights > 0) {
+            // XZRect::pdf_value, hitable.rs:245-254 (its hit test uses 0.001 and f64::MAX)
+            if (STATS) cnt.light_tests++;
+            float lp = 0.0f;
+            const float t = (S.light.f[4] - sf.p.y) / dir.y;
+            const float lx = fmaf(t, dir.x, sf.p.x), lz = fmaf(t, dir.z, sf.p.z);
+            const bool miss = (t < 0.001f) | (t > 3.402823466e+38f) | (lx < S.light.f[0]) | (lx > S.light.f[1]) | (lz < S.light.f[2]) | (lz > S.light.f[3]);
+            if (!miss) {
+              const float area = (S.light.f[1] - S.light.f[0]) * (S.light.f[3] - S.light.f[2]);
+              const float cosine = fabsf(dir.y * inv_len);
+              lp = (t * t * dlen2) / (cosine * area);
+            }
+            pdf_val = 0.5f * lp + 0.5f * pdf_val;
+          }
+          // material.rs:76-82
+          float cos_n = dot3(sf.normal, dir) * inv_len;
+          if (cos_n < 0.0f) cos_n = 0.0f;
+          const float f = (cos_n * (1.0f / RT_PI_F)) / pdf_val;
+          thr = f3(thr.x * albedo.x * f, thr.y * albedo.y * f, thr.z * albedo.z * f);
+          // A zero or NaN weight fixes the sample's value (0 after de_nan) whatever
+          // the rest of the path does, so the path ends here.
+          const bool dead_weight = !(thr.x > 0.0f || thr.y > 0.0f || thr.z > 0.0f);
+          if (!dead_weight) {
+            ray = make_ray(sf.p, dir);
+            depth += 1;
+            done = false;
+          }
+        }
+      }
+      if (done) {
+        // de_nan (main.rs:252-264) then col += (main.rs:108)
+        const float r = radiance.x != radiance.x ? 0.0f : radiance.x;
+        const float g = radiance.y != radiance.y ? 0.0f : radiance.y;
+        const float b = radiance.z != radiance.z ? 0.0f : radiance.z;
+        if (r != 0.0f || g != 0.0f || b != 0.0f) {
+          atomicAdd(&acc[wib][0][pix], r);
+          atomicAdd(&acc[wib][1][pix], g);
+          atomicAdd(&acc[wib][2][pix], b);
+          if (SUMSQ) {
+            atomicAdd(&acc[wib][3][pix], r * r);
+            atomicAdd(&acc[wib][4][pix], g * g);
+            atomicAdd(&acc[wib][5][pix], b * b);
+          }
+        }
+        alive = false;
+      }
+    }
+  }
+
+  // ---- write the tile (main.rs:112-114; sums, not means) ----
+  {
+    const int px = tx * 8 + (lane & 7);
+    const int row = ty * 8 + (lane >> 3);
+    if (px < A.nx && row < A.ny) {
+      const size_t at = ((size_t)row * A.nx + px) * 3;
+      out_sum[at] = acc[wib][0][lane];
+      out_sum[at + 1] = acc[wib][1][lane];
+      out_sum[at + 2] = acc[wib][2][lane];
+      if (SUMSQ) {
+        out_sumsq[at] = acc[wib][3][lane];
+        out_sumsq[at + 1] = acc[wib][4][lane];
+        out_sumsq[at + 2] = acc[wib][5][lane];
+      }
+    }
+  }
+  if (STATS) {
+    unsigned long long v[9] = {cnt.paths, cnt.rays, cnt.hits, cnt.node_tests, cnt.rect_tests, cnt.sphere_tests, cnt.instance_ops, cnt.shade_events, cnt.light_tests};
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      unsigned long long x = v[k];
+      for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off, 64);
+      if (lane == 0) atomicAdd(&stats[k], x);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// tonemap_kernel (main.rs:136-155)
+// ---------------------------------------------------------------------------
+__global__ void tonemap_kernel(const float* __restrict__ sum, size_t n, float spp, unsigned char* __restrict__ out) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float c = sqrtf(sum[i] / spp);
+  if (c > 1.0f) c = 1.0f;
+  const float x = 255.99f * c;
+  // `as u8`: saturating, NaN -> 0
+  unsigned char b = 0;
+  if (x > 0.0f) b = x >= 255.0f ? 255 : (unsigned char)x;
+  out[i] = b;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------
+// Host side of the ABI
+// ---------------------------------------------------------------------------
+struct rt_ctx {
+  int device;
+  bool has_scene;
+  DevScene dev;
+  void* d_scan;
+  void* d_prims;
+  void* d_objects;
+  void* d_materials;
+  void* d_textures;
+  void* d_perlins;
+  unsigned long long* d_stats;
+  hipEvent_t ev0, ev1;
+};
+
+namespace {
+
+int hip_fail(hipError_t e, const char* what) {
+  return rt::set_error(RT_ERR_DEVICE, std::string(what) + ": " + hipGetErrorString(e));
+}
+
+#define HIP_TRY(expr)                                  \
+  do {                                                 \
+    hipError_t e_ = (expr);                            \
+    if (e_ != hipSuccess) return hip_fail(e_, #expr); \
+  } while (0)
+
+void free_scene(rt_ctx* ctx) {
+  void** ptrs[] = {&ctx->d_scan, &ctx->d_prims, &ctx->d_objects, &ctx->d_materials, &ctx->d_textures, &ctx->d_perlins};
+  for (size_t i = 0; i < sizeof(ptrs) / sizeof(ptrs[0]); ++i) {
+    if (*ptrs[i]) (void)hipFree(*ptrs[i]);
+    *ptrs[i] = nullptr;
+  }
+  ctx->has_scene = false;
+}
+
+// Checks every index the kernels follow, so a malformed scene is an error
+// return instead of an out-of-bounds access on the device.
+int validate_scene(const rt_scene* s) {
+  if (!s) return rt::set_error(RT_ERR_INVALID, "scene is null");
+  if (s->n_nodes <= 0 || !s->nodes) return rt::set_error(RT_ERR_INVALID, "scene has no nodes");
+  if (s->n_prims <= 0 || !s->prims) return rt::set_error(RT_ERR_INVALID, "scene has no primitives");
+  if (s->n_materials <= 0 || !s->materials) return rt::set_error(RT_ERR_INVALID, "scene has no materials");
+  if (s->n_textures < 0 || s->n_objects < 0 || s->n_perlins < 0) return rt::set_error(RT_ERR_INVALID, "negative count");
+  if (s->n_lights < 0 || s->n_lights > 1) return rt::set_error(RT_ERR_UNSUPPORTED, "n_lights must be 0 or 1");
+  if (s->n_lights == 1 && s->lights[0].type != RT_LIGHT_XZ_RECT) return rt::set_error(RT_ERR_UNSUPPORTED, "light type must be RT_LIGHT_XZ_RECT");
+  for (int i = 0; i < s->n_textures; ++i) {
+    const rt_texture& t = s->textures[i];
+    if (t.type != RT_TEX_CONSTANT) return rt::set_error(RT_ERR_UNSUPPORTED, "this build renders constant textures only");
+  }
+  for (int i = 0; i < s->n_materials; ++i) {
+    const rt_material& m = s->materials[i];
+    if (m.type != RT_MAT_LAMBERTIAN && m.type != RT_MAT_DIFFUSE_LIGHT)
+      return rt::set_error(RT_ERR_UNSUPPORTED, "this build renders Lambertian and DiffuseLight materials only");
+    if (m.texture < 0 || m.texture >= s->n_textures) return rt::set_error(RT_ERR_INVALID, "material texture index out of range");
+  }
+  for (int i = 0; i < s->n_prims; ++i) {
+    const rt_prim& p = s->prims[i];
+    const int type = p.type & RT_PRIM_TYPE_MASK;
+    if (type < RT_PRIM_SPHERE || type > RT_PRIM_YZ_RECT) return rt::set_error(RT_ERR_INVALID, "unknown primitive type");
+    if ((p.type & ~(RT_PRIM_TYPE_MASK | RT_PRIM_FLIP)) != 0) return rt::set_error(RT_ERR_INVALID, "unknown primitive flag");
+    if (p.material < 0 || p.material >= s->n_materials) return rt::set_error(RT_ERR_INVALID, "primitive material index out of range");
+  }
+  for (int i = 0; i < s->n_objects; ++i) {
+    const rt_object& o = s->objects[i];
+    if (o.kind == RT_OBJ_MEDIUM) return rt::set_error(RT_ERR_UNSUPPORTED, "this build does not render ConstantMedium objects");
+    if (o.kind == RT_OBJ_LIST) {
+      if (o.first < 0 || o.count <= 0 || o.first + o.count > s->n_prims) return rt::set_error(RT_ERR_INVALID, "object primitive range out of bounds");
+    } else if (o.kind == RT_OBJ_BVH) {
+      if (o.first <= 0 || o.first >= s->n_nodes) return rt::set_error(RT_ERR_INVALID, "object sub-tree root out of range");
+    } else {
+      return rt::set_error(RT_ERR_INVALID, "unknown object kind");
+    }
+  }
+  return RT_OK;
+}
+
+// Depth-first re-layout of the breadth-first node array.  `in_sub` marks nodes
+// of a BvhNode used as a child hitable, whose leaves must be primitive leaves.
+int build_scan(const rt_scene* s, int idx, bool in_sub, int depth, std::vector<ScanNode>* out) {
+  if (idx < 0 || idx >= s->n_nodes) return rt::set_error(RT_ERR_INVALID, "node index out of range");
+  if (depth > 64) return rt::set_error(RT_ERR_INVALID, "node tree deeper than 64 levels (cycle?)");
+  if ((int)out->size() > 4 * s->n_nodes + 16) return rt::set_error(RT_ERR_INVALID, "node array is not a tree");
+  const rt_node& n = s->nodes[idx];
+  const size_t at = out->size();
+  ScanNode sn;
+  std::memset(&sn, 0, sizeof(sn));
+  for (int c = 0; c < 3; ++c) { sn.bmin[c] = n.bmin[c]; sn.bmax[c] = n.bmax[c]; }
+  out->push_back(sn);
+  if (n.left < 0) {
+    const int ref = ~n.left;
+    if (n.right > 0) {
+      if (ref < 0 || ref + n.right > s->n_prims) return rt::set_error(RT_ERR_INVALID, "leaf primitive range out of bounds");
+      (*out)[at].kind = SCAN_PRIMS;
+      (*out)[at].a = ref;
+      (*out)[at].b = n.right;
+    } else if (n.right == 0) {
+      if (in_sub) return rt::set_error(RT_ERR_UNSUPPORTED, "objects inside an object's sub-tree are not supported");
+      if (ref < 0 || ref >= s->n_objects) return rt::set_error(RT_ERR_INVALID, "leaf object index out of range");
+      (*out)[at].kind = SCAN_OBJECT;
+      (*out)[at].a = ref;
+      if (s->objects[ref].kind == RT_OBJ_BVH) {
+        const int rc = build_scan(s, s->objects[ref].first, true, depth + 1, out);
+        if (rc != RT_OK) return rc;
+      }
+    } else {
+      return rt::set_error(RT_ERR_INVALID, "leaf with negative count");
+    }
+  } else {
+    if (n.right < 0) return rt::set_error(RT_ERR_INVALID, "interior node with a negative right child");
+    (*out)[at].kind = SCAN_INTERIOR;
+    int rc = build_scan(s, n.left, in_sub, depth + 1, out);
+    if (rc != RT_OK) return rc;
+    rc = build_scan(s, n.right, in_sub, depth + 1, out);
+    if (rc != RT_OK) return rc;
+  }
+  (*out)[at].skip = (int)out->size();
+  return RT_OK;
+}
+
+template <class T> int upload(void** dst, const T* src, size_t n) {
+  *dst = nullptr;
+  const size_t bytes = (n ? n : 1) * sizeof(T);
+  HIP_TRY(hipMalloc(dst, bytes));
+  if (n) HIP_TRY(hipMemcpy(*dst, src, n * sizeof(T), hipMemcpyHostToDevice));
+  return RT_OK;
+}
+
+int check_params(const rt_render_params* p) {
+  if (!p) return rt::set_error(RT_ERR_INVALID, "params is null");
+  if (p->nx <= 0 || p->ny <= 0 || p->nx > 32768 || p->ny > 32768) return rt::set_error(RT_ERR_INVALID, "image size out of range");
+  if (p->spp <= 0 || p->spp > (1 << 24) || p->sample_begin < 0) return rt::set_error(RT_ERR_INVALID, "spp out of range (1 .. 2^24)");
+  if (p->max_depth < 0 || p->max_depth > 1000) return rt::set_error(RT_ERR_INVALID, "max_depth out of range");
+  if (p->sky != RT_SKY_BLACK && p->sky != RT_SKY_GRADIENT) return rt::set_error(RT_ERR_INVALID, "unknown sky mode");
+  if (p->shard_count < 1 || p->shard_index < 0 || p->shard_index >= p->shard_count) return rt::set_error(RT_ERR_INVALID, "bad shard_index/shard_count");
+  return RT_OK;
+}
+
+DevCamera to_dev_camera(const rt_camera* c) {
+  DevCamera d;
+  for (int k = 0; k < 3; ++k) {
+    d.origin[k] = (float)c->origin[k];
+    d.llc[k] = (float)c->lower_left_corner[k];
+    d.horizontal[k] = (float)c->horizontal[k];
+    d.vertical[k] = (float)c->vertical[k];
+    d.u[k] = (float)c->u[k];
+    d.v[k] = (float)c->v[k];
+  }
+  d.lens_radius = (float)c->lens_radius;
+  return d;
+}
+
+int launch_render(rt_ctx* ctx, const rt_camera* cam, const rt_render_params* p, float* d_sum, float* d_sumsq, bool stats, hipStream_t stream) {
+  RenderArgs A;
+  A.nx = p->nx; A.ny = p->ny; A.spp = p->spp; A.sample_begin = p->sample_begin; A.max_depth = p->max_depth; A.sky = p->sky;
+  A.t_min = p->t_min; A.shard_index = p->shard_index; A.shard_count = p->shard_count;
+  A.key0 = (unsigned)p->seed; A.key1 = (unsigned)(p->seed >> 32);
+  A.tiles_x = (p->nx + 7) / 8; A.tiles_y = (p->ny + 7) / 8;
+  const size_t n = (size_t)p->nx * p->ny * 3;
+  if (p->shard_count > 1) {
+    HIP_TRY(hipMemsetAsync(d_sum, 0, n * sizeof(float), stream));
+    if (d_sumsq) HIP_TRY(hipMemsetAsync(d_sumsq, 0, n * sizeof(float), stream));
+  }
+  const DevCamera dc = to_dev_camera(cam);
+  const int n_tiles = A.tiles_x * A.tiles_y;
+  const dim3 grid((n_tiles + 3) / 4), block(256);
+  if (stats) {
+    if (d_sumsq) hipLaunchKernelGGL((render_kernel<true, true>), grid, block, 0, stream, ctx->dev, dc, A, d_sum, d_sumsq, ctx->d_stats);
+    else hipLaunchKernelGGL((render_kernel<true, false>), grid, block, 0, stream, ctx->dev, dc, A, d_sum, d_sumsq, ctx->d_stats);
+  } else {
+    if (d_sumsq) hipLaunchKernelGGL((render_kernel<false, true>), grid, block, 0, stream, ctx->dev, dc, A, d_sum, d_sumsq, ctx->d_stats);
+    else hipLaunchKernelGGL((render_kernel<false, false>), grid, block, 0, stream, ctx->dev, dc, A, d_sum, d_sumsq, ctx->d_stats);
+  }
+  HIP_TRY(hipGetLastError());
+  return RT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rt_create(int device_id, rt_ctx** out) {
+  if (!out) return rt::set_error(RT_ERR_INVALID, "rt_create: null out");
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count <= 0) return rt::set_error(RT_ERR_DEVICE, "rt_create: no HIP device available (this library has no CPU path)");
+  if (device_id < 0 || device_id >= count) return rt::set_error(RT_ERR_INVALID, "rt_create: device id out of range");
+  HIP_TRY(hipSetDevice(device_id));
+  rt_ctx* ctx = new rt_ctx();
+  std::memset(ctx, 0, sizeof(*ctx));
+  ctx->device = device_id;
+  e = hipMalloc((void**)&ctx->d_stats, 9 * sizeof(unsigned long long));
+  if (e == hipSuccess) e = hipEventCreate(&ctx->ev0);
+  if (e == hipSuccess) e = hipEventCreate(&ctx->ev1);
+  if (e != hipSuccess) {
+    delete ctx;
+    return hip_fail(e, "rt_create");
+  }
+  *out = ctx;
+  return RT_OK;
+}
+
+int rt_destroy(rt_ctx* ctx) {
+  if (!ctx) return RT_OK;
+  (void)hipSetDevice(ctx->device);
+  free_scene(ctx);
+  if (ctx->d_stats) (void)hipFree(ctx->d_stats);
+  if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+  if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+  delete ctx;
+  return RT_OK;
+}
+
+int rt_upload_scene(rt_ctx* ctx, const rt_scene* s) {
+  if (!ctx) return rt::set_error(RT_ERR_INVALID, "rt_upload_scene: null context");
+  int rc = validate_scene(s);
+  if (rc != RT_OK) return rc;
+  std::vector<ScanNode> scan;
+  rc = build_scan(s, 0, false, 0, &scan);
+  if (rc != RT_OK) return rc;
+  HIP_TRY(hipSetDevice(ctx->device));
+  free_scene(ctx);
+  if ((rc = upload(&ctx->d_scan, scan.data(), scan.size())) != RT_OK) return rc;
+  if ((rc = upload(&ctx->d_prims, s->prims, (size_t)s->n_prims)) != RT_OK) return rc;
+  if ((rc = upload(&ctx->d_objects, s->objects, (size_t)s->n_objects)) != RT_OK) return rc;
+  if ((rc = upload(&ctx->d_materials, s->materials, (size_t)s->n_materials)) != RT_OK) return rc;
+  if ((rc = upload(&ctx->d_textures, s->textures, (size_t)s->n_textures)) != RT_OK) return rc;
+  if ((rc = upload(&ctx->d_perlins, s->perlins, (size_t)s->n_perlins)) != RT_OK) return rc;
+  DevScene& d = ctx->dev;
+  std::memset(&d, 0, sizeof(d));
+  d.scan = (const ScanNode*)ctx->d_scan;
+  d.prims = (const rt_prim*)ctx->d_prims;
+  d.objects = (const rt_object*)ctx->d_objects;
+  d.materials = (const rt_material*)ctx->d_materials;
+  d.textures = (const rt_texture*)ctx->d_textures;
+  d.perlins = (const rt_perlin*)ctx->d_perlins;
+  d.n_scan = (int)scan.size();
+  d.n_prims = s->n_prims;
+  d.n_objects = s->n_objects;
+  d.n_lights = s->n_lights;
+  if (s->n_lights > 0) d.light = s->lights[0];
+  ctx->has_scene = true;
+  return RT_OK;
+}
+
+int rt_render_device(rt_ctx* ctx, const rt_camera* cam, const rt_render_params* params, float* d_sum, float* d_sumsq, void* hip_stream) {
+  if (!ctx || !cam || !d_sum) return rt::set_error(RT_ERR_INVALID, "rt_render_device: null argument");
+  if (!ctx->has_scene) return rt::set_error(RT_ERR_NO_SCENE, "rt_render_device: no scene uploaded");
+  const int rc = check_params(params);
+  if (rc != RT_OK) return rc;
+  HIP_TRY(hipSetDevice(ctx->device));
+  return launch_render(ctx, cam, params, d_sum, d_sumsq, false, (hipStream_t)hip_stream);
+}
+
+int rt_render(rt_ctx* ctx, const rt_camera* cam, const rt_render_params* params, float* out_sum, float* out_sumsq, rt_stats* stats) {
+  if (!ctx || !cam || !out_sum) return rt::set_error(RT_ERR_INVALID, "rt_render: null argument");
+  if (!ctx->has_scene) return rt::set_error(RT_ERR_NO_SCENE, "rt_render: no scene uploaded");
+  int rc = check_params(params);
+  if (rc != RT_OK) return rc;
+  HIP_TRY(hipSetDevice(ctx->device));
+  const size_t bytes = (size_t)params->nx * params->ny * 3 * sizeof(float);
+  float *d_sum = nullptr, *d_sumsq = nullptr;
+  HIP_TRY(hipMalloc((void**)&d_sum, bytes));
+  if (out_sumsq) {
+    hipError_t e = hipMalloc((void**)&d_sumsq, bytes);
+    if (e != hipSuccess) { (void)hipFree(d_sum); return hip_fail(e, "hipMalloc"); }
+  }
+  hipError_t e = hipSuccess;
+  if (stats) e = hipMemset(ctx->d_stats, 0, 9 * sizeof(unsigned long long));
+  if (e == hipSuccess) e = hipEventRecord(ctx->ev0, 0);
+  rc = RT_OK;
+  if (e == hipSuccess) rc = launch_render(ctx, cam, params, d_sum, d_sumsq, stats != nullptr, 0);
+  if (e == hipSuccess && rc == RT_OK) e = hipEventRecord(ctx->ev1, 0);
+  if (e == hipSuccess && rc == RT_OK) e = hipEventSynchronize(ctx->ev1);
+  if (e == hipSuccess && rc == RT_OK) e = hipMemcpy(out_sum, d_sum, bytes, hipMemcpyDeviceToHost);
+  if (e == hipSuccess && rc == RT_OK && out_sumsq) e = hipMemcpy(out_sumsq, d_sumsq, bytes, hipMemcpyDeviceToHost);
+  if (e == hipSuccess && rc == RT_OK && stats) {
+    unsigned long long v[9];
+    e = hipMemcpy(v, ctx->d_stats, sizeof(v), hipMemcpyDeviceToHost);
+    if (e == hipSuccess) {
+      std::memset(stats, 0, sizeof(*stats));
+      stats->paths = v[0]; stats->rays = v[1]; stats->hits = v[2]; stats->node_tests = v[3]; stats->rect_tests = v[4];
+      stats->sphere_tests = v[5]; stats->instance_ops = v[6]; stats->shade_events = v[7]; stats->light_tests = v[8];
+      float ms = 0.0f;
+      e = hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
+      stats->kernel_ms = ms;
+    }
+  }
+  (void)hipFree(d_sum);
+  if (d_sumsq) (void)hipFree(d_sumsq);
+  if (rc != RT_OK) return rc;
+  if (e != hipSuccess) return hip_fail(e, "rt_render");
+  return RT_OK;
+}
+
+int rt_trace_closest(rt_ctx* ctx, const float* o, const float* d, size_t n, float t_min, float t_max, int32_t* prim_id, float* t,
+                     float* normal, float* p) {
+  if (!ctx || !o || !d || !prim_id || !t) return rt::set_error(RT_ERR_INVALID, "rt_trace_closest: null argument");
+  if (!ctx->has_scene) return rt::set_error(RT_ERR_NO_SCENE, "rt_trace_closest: no scene uploaded");
+  if (n == 0) return RT_OK;
+  HIP_TRY(hipSetDevice(ctx->device));
+  float *d_o = nullptr, *d_d = nullptr, *d_t = nullptr, *d_n = nullptr, *d_p = nullptr;
+  int* d_id = nullptr;
+  hipError_t e = hipMalloc((void**)&d_o, n * 3 * sizeof(float));
+  if (e == hipSuccess) e = hipMalloc((void**)&d_d, n * 3 * sizeof(float));
+  if (e == hipSuccess) e = hipMalloc((void**)&d_t, n * sizeof(float));
+  if (e == hipSuccess) e = hipMalloc((void**)&d_id, n * sizeof(int));
+  if (e == hipSuccess && normal) e = hipMalloc((void**)&d_n, n * 3 * sizeof(float));
+  if (e == hipSuccess && p) e = hipMalloc((void**)&d_p, n * 3 * sizeof(float));
+  if (e == hipSuccess) e = hipMemcpy(d_o, o, n * 3 * sizeof(float), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(d_d, d, n * 3 * sizeof(float), hipMemcpyHostToDevice);
+  if (e == hipSuccess) {
+    size_t blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(trace_kernel, dim3((unsigned)blocks), dim3(256), 0, 0, ctx->dev, d_o, d_d, n, t_min, t_max, d_id, d_t, d_n, d_p);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipDeviceSynchronize();
+  if (e == hipSuccess) e = hipMemcpy(prim_id, d_id, n * sizeof(int), hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = hipMemcpy(t, d_t, n * sizeof(float), hipMemcpyDeviceToHost);
+  if (e == hipSuccess && normal) e = hipMemcpy(normal, d_n, n * 3 * sizeof(float), hipMemcpyDeviceToHost);
+  if (e == hipSuccess && p) e = hipMemcpy(p, d_p, n * 3 * sizeof(float), hipMemcpyDeviceToHost);
+  void* ptrs[] = {d_o, d_d, d_t, d_id, d_n, d_p};
+  for (size_t i = 0; i < 6; ++i)
+    if (ptrs[i]) (void)hipFree(ptrs[i]);
+  if (e != hipSuccess) return hip_fail(e, "rt_trace_closest");
+  return RT_OK;
+}
+
+int rt_tonemap(rt_ctx* ctx, const float* sum_rgb, int32_t nx, int32_t ny, int32_t spp_total, uint8_t* rgb8) {
+  if (!ctx || !sum_rgb || !rgb8 || nx <= 0 || ny <= 0 || spp_total <= 0) return rt::set_error(RT_ERR_INVALID, "rt_tonemap: bad argument");
+  HIP_TRY(hipSetDevice(ctx->device));
+  const size_t n = (size_t)nx * ny * 3;
+  float* d_in = nullptr;
+  unsigned char* d_out = nullptr;
+  hipError_t e = hipMalloc((void**)&d_in, n * sizeof(float));
+  if (e == hipSuccess) e = hipMalloc((void**)&d_out, n);
+  if (e == hipSuccess) e = hipMemcpy(d_in, sum_rgb, n * sizeof(float), hipMemcpyHostToDevice);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(tonemap_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, d_in, n, (float)spp_total, d_out);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpy(rgb8, d_out, n, hipMemcpyDeviceToHost);
+  if (d_in) (void)hipFree(d_in);
+  if (d_out) (void)hipFree(d_out);
+  if (e != hipSuccess) return hip_fail(e, "rt_tonemap");
+  return RT_OK;
+}
+
+}  // extern "C"

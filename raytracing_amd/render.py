@@ -1,0 +1,102 @@
+"""The sample loop of src/main.rs:67-133 behind the C ABI.
+
+`Renderer` wraps one rt_ctx (one GPU).  There is no CPU implementation here:
+every method ends in a call into librt_amd.so and raises RtError when the
+library or the device is not usable.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import check, make_params
+
+
+class Renderer(object):
+    def __init__(self, device_id=0):
+        self._ctx = C.c_void_p()
+        check(_lib.lib().rt_create(device_id, C.byref(self._ctx)))
+        self.device_id = device_id
+
+    def close(self):
+        if self._ctx:
+            _lib.lib().rt_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def upload_scene(self, flat_scene):
+        check(_lib.lib().rt_upload_scene(self._ctx, C.byref(flat_scene)))
+
+    def render(self, camera, params, want_sumsq=False, want_stats=False):
+        """Blocking render to host arrays: per-pixel sums, shape (ny, nx, 3),
+        top row first; optionally sums of squares and the event counters."""
+        shape = (params.ny, params.nx, 3)
+        s = np.zeros(shape, dtype=np.float32)
+        s2 = np.zeros(shape, dtype=np.float32) if want_sumsq else None
+        stats = _lib.rt_stats() if want_stats else None
+        check(_lib.lib().rt_render(self._ctx, C.byref(camera.c), C.byref(params), s.ctypes.data,
+                                   s2.ctypes.data if want_sumsq else None,
+                                   C.byref(stats) if want_stats else None))
+        out = [s]
+        if want_sumsq:
+            out.append(s2)
+        if want_stats:
+            out.append(stats)
+        return tuple(out) if len(out) > 1 else s
+
+    def render_device(self, camera, params, d_sum_ptr, d_sumsq_ptr=None, stream=None):
+        """Enqueues the render on `stream` (a hipStream_t as int) writing into
+        device memory the caller owns (for example a torch tensor's data_ptr())."""
+        check(_lib.lib().rt_render_device(self._ctx, C.byref(camera.c), C.byref(params), C.c_void_p(d_sum_ptr),
+                                          C.c_void_p(d_sumsq_ptr) if d_sumsq_ptr else None,
+                                          C.c_void_p(stream) if stream else None))
+
+    def trace_closest(self, o, d, t_min=0.001, t_max=float("inf"), want_normal=False, want_p=False):
+        """world.hit(r, t_min, t_max) of main.rs:166 for a batch of rays."""
+        o = np.ascontiguousarray(o, dtype=np.float32)
+        d = np.ascontiguousarray(d, dtype=np.float32)
+        if o.ndim != 2 or o.shape[1] != 3 or o.shape != d.shape:
+            raise ValueError("o and d must both have shape (n, 3)")
+        n = o.shape[0]
+        prim = np.zeros(n, dtype=np.int32)
+        t = np.zeros(n, dtype=np.float32)
+        normal = np.zeros((n, 3), dtype=np.float32) if want_normal else None
+        p = np.zeros((n, 3), dtype=np.float32) if want_p else None
+        check(_lib.lib().rt_trace_closest(self._ctx, o.ctypes.data, d.ctypes.data, n, t_min, t_max, prim.ctypes.data,
+                                          t.ctypes.data, normal.ctypes.data if want_normal else None,
+                                          p.ctypes.data if want_p else None))
+        out = [prim, t]
+        if want_normal:
+            out.append(normal)
+        if want_p:
+            out.append(p)
+        return tuple(out)
+
+    def tonemap(self, sum_rgb, spp_total):
+        """main.rs:136-155 on the device: u8 RGB, shape (ny, nx, 3)."""
+        a = np.ascontiguousarray(sum_rgb, dtype=np.float32)
+        ny, nx = a.shape[0], a.shape[1]
+        out = np.zeros((ny, nx, 3), dtype=np.uint8)
+        check(_lib.lib().rt_tonemap(self._ctx, a.ctypes.data, nx, ny, spp_total, out.ctypes.data))
+        return out
+
+
+def render_image(scene, camera, world, nx, ny, ns, seed=0x5EED0001, light_shape=None, device_id=0):
+    """main(): flatten `world`, render ns samples per pixel, return the 8-bit
+    image (main.rs:65-155).  `light_shape` = (x0, x1, z0, z1, k) is the XZRect
+    color() samples (main.rs:177-178); None renders with CosinePDF alone."""
+    if light_shape is not None:
+        scene.light_xz_rect(*light_shape)
+    flat = scene.flatten(world)
+    r = Renderer(device_id)
+    try:
+        r.upload_scene(flat)
+        sums = r.render(camera, make_params(nx, ny, ns, seed=seed))
+        return r.tonemap(sums, ns)
+    finally:
+        r.close()

@@ -1,0 +1,102 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def orc():
+    """The CPU oracle (test infrastructure): oracle/liboracle.so through ctypes."""
+    from oracle import binding
+    binding.lib()
+    return binding
+
+
+class CornellFixture(object):
+    def __init__(self, seed=0x5EED0001, ratio=1.0):
+        from raytracing_amd import Scene
+        from raytracing_amd.scenes import MAIN_RS_LIGHT_SHAPE, cornell_box_scene
+        self.scene = Scene(seed)
+        with self.scene:
+            self.camera, self.world = cornell_box_scene(ratio)
+            self.scene.light_xz_rect(*MAIN_RS_LIGHT_SHAPE)
+            self.flat = self.scene.flatten(self.world)
+
+
+@pytest.fixture(scope="session")
+def cornell():
+    """cornell_box_scene(1.0) (scenes.rs:276-360) flattened, with the light
+    shape of main.rs:177-178 registered for HitablePDF."""
+    return CornellFixture()
+
+
+@pytest.fixture(scope="session")
+def gpu():
+    """One Renderer on device 0.  Fails (does not skip) when the HIP library or
+    the device is missing: GPU tests must not pass on a fallback."""
+    from raytracing_amd import Renderer
+    r = Renderer(0)
+    yield r
+    r.close()
+
+
+def cornell_ray_batch(cornell, n, seed):
+    """Seeded rays for nearest-hit parity in the Cornell box: camera rays,
+    rays from random interior points in random directions (what cosine bounces
+    look like), axis-aligned rays and rays aimed at primitive edges/corners."""
+    rng = np.random.RandomState(seed)
+    cam = cornell.camera.c
+    origin = np.array(list(cam.origin))
+    llc = np.array(list(cam.lower_left_corner))
+    hor = np.array(list(cam.horizontal))
+    ver = np.array(list(cam.vertical))
+    n_cam = n // 3
+    n_int = n // 3
+    n_axis = n // 12
+    n_edge = n - n_cam - n_int - n_axis
+    os_, ds_ = [], []
+    # camera rays (camera.rs:53-62 with aperture 0)
+    s = rng.rand(n_cam, 1)
+    t = rng.rand(n_cam, 1)
+    os_.append(np.repeat(origin[None, :], n_cam, axis=0))
+    ds_.append(llc[None, :] + s * hor[None, :] + t * ver[None, :] - origin[None, :])
+    # interior bounce-like rays
+    os_.append(rng.rand(n_int, 3) * 555.0)
+    d = rng.randn(n_int, 3)
+    ds_.append(d * rng.uniform(0.1, 3.0, size=(n_int, 1)))
+    # axis-aligned rays (zero components in the direction)
+    o = rng.rand(n_axis, 3) * 555.0
+    d = np.zeros((n_axis, 3))
+    ax = rng.randint(0, 3, size=n_axis)
+    d[np.arange(n_axis), ax] = rng.choice([-1.0, 1.0], size=n_axis) * rng.uniform(0.5, 2.0, size=n_axis)
+    os_.append(o)
+    ds_.append(d)
+    # rays aimed from interior points at corners/edges of the boxes and walls (world-space AABB corners
+    # of every node), jittered by a few ulps to straddle the edges
+    flat = cornell.flat
+    targets = []
+    for i in range(flat.n_nodes):
+        nd = flat.nodes[i]
+        for cx in (nd.bmin[0], nd.bmax[0]):
+            for cy in (nd.bmin[1], nd.bmax[1]):
+                for cz in (nd.bmin[2], nd.bmax[2]):
+                    targets.append((cx, cy, cz))
+    targets = np.array(targets)
+    o = rng.rand(n_edge, 3) * 500.0 + 25.0
+    tgt = targets[rng.randint(0, len(targets), size=n_edge)] + rng.randn(n_edge, 3) * rng.choice([0.0, 1e-4, 1e-2, 1.0], size=(n_edge, 1))
+    os_.append(o)
+    ds_.append(tgt - o)
+    o = np.concatenate(os_).astype(np.float32)
+    d = np.concatenate(ds_).astype(np.float32)
+    return o, d

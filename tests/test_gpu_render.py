@@ -1,0 +1,135 @@
+"""Parity of the HIP sample loop (rt_render through the C ABI) against the CPU
+oracle.  Monte Carlo sums cannot be compared bit for bit with the reference
+(its random numbers are OS seeded), so the bars are statistical, as
+BASELINE.json's north_star states: per channel within 3 standard errors,
+RMSE below a stated threshold, at equal sample counts."""
+import numpy as np
+import pytest
+
+from raytracing_amd import _lib, make_params
+
+pytestmark = pytest.mark.gpu
+
+
+def _z_scores(sum_a, sumsq_a, sum_b, sumsq_b, n):
+    """Per pixel and channel: difference of the two means over the standard
+    error of that difference, from each side's own sample variance."""
+    ma, mb = sum_a / n, sum_b / n
+    va = np.maximum(sumsq_a - n * ma * ma, 0.0) / (n - 1)  # sample variance of one sample
+    vb = np.maximum(sumsq_b - n * mb * mb, 0.0) / (n - 1)
+    se = np.sqrt(va / n + vb / n)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        z = (ma - mb) / se
+    return ma, mb, se, z
+
+
+def test_render_same_stream_tracks_oracle(gpu, orc, cornell):
+    """Same Philox seed on both sides: the device draws exactly the oracle's
+    random numbers, so the only differences are fp32 rounding in shading and the
+    hardware sin/cos.  Nearly every pixel sum then agrees to fp32 accuracy; the
+    few that do not are paths that a last-bit difference sent to another surface."""
+    gpu.upload_scene(cornell.flat)
+    nx = ny = 64
+    spp = 32
+    params = make_params(nx, ny, spp, seed=0xC0FFEE)
+    s, s2, stats = gpu.render(cornell.camera, params, want_sumsq=True, want_stats=True)
+    os_, os2, ostats = orc.render(cornell.flat, cornell.camera.c, params, mode=orc.ORC_F32_FUSED, want_stats=True)
+    assert stats.paths == nx * ny * spp == ostats.paths
+    assert np.isfinite(s).all() and (s >= 0).all()
+    close = np.isclose(s, os_, rtol=2e-4, atol=1e-4)
+    assert close.mean() > 0.98, close.mean()
+    # whole-image energy agrees tightly
+    assert abs(s.sum() - os_.sum()) / os_.sum() < 2e-3
+    # the device ends a path whose weight reached zero; the oracle follows it to the end
+    assert stats.rays <= ostats.rays and stats.rays > 0.8 * ostats.rays
+    assert stats.shade_events == stats.light_tests
+    assert stats.kernel_ms > 0
+
+
+def test_render_statistical_parity_independent_seeds(gpu, orc, cornell):
+    """Independent seeds, equal spp, f64 oracle (the reference's arithmetic):
+    per-channel differences within 3 standard errors for all but the share of
+    pixels a normal distribution puts beyond 3 sigma (0.27 %; 1 % allowed because
+    per-pixel variance is itself estimated from 256 heavy-tailed samples), no mean
+    bias, and RMSE of the difference consistent with pure Monte Carlo noise."""
+    gpu.upload_scene(cornell.flat)
+    nx = ny = 64
+    spp = 256
+    s, s2 = gpu.render(cornell.camera, make_params(nx, ny, spp, seed=1111), want_sumsq=True)
+    os_, os2 = orc.render(cornell.flat, cornell.camera.c, make_params(nx, ny, spp, seed=2222), mode=orc.ORC_F64)
+    ma, mb, se, z = _z_scores(s.astype(np.float64), s2.astype(np.float64), os_, os2, spp)
+    valid = se > 0
+    assert valid.mean() > 0.7
+    zz = z[valid]
+    assert (np.abs(zz) > 3).mean() < 0.01, (np.abs(zz) > 3).mean()
+    assert abs(zz.mean()) < 0.05, zz.mean()
+    assert 0.9 < zz.std() < 1.1, zz.std()
+    # RMSE threshold: the difference image's RMSE must not exceed 1.15x what the two noise levels predict
+    rmse = np.sqrt(((ma - mb)[valid] ** 2).mean())
+    predicted = np.sqrt((se[valid] ** 2).mean())
+    assert rmse < 1.15 * predicted, (rmse, predicted)
+    # pixels neither side ever lit (the black frame) are exactly zero on both
+    assert np.all(ma[~valid] == mb[~valid])
+    # image means agree to 1 %
+    assert abs(ma.mean() - mb.mean()) / mb.mean() < 0.01
+
+
+def test_render_sample_ranges_and_repeatability(gpu, cornell):
+    """Sample-range sharding: two ranges add up to the whole (to fp32 summation
+    order), and the same call twice gives the same bits."""
+    gpu.upload_scene(cornell.flat)
+    cam = cornell.camera
+    whole = gpu.render(cam, make_params(72, 40, 24, seed=5))
+    again = gpu.render(cam, make_params(72, 40, 24, seed=5))
+    assert np.array_equal(whole, again)
+    lo = gpu.render(cam, make_params(72, 40, 10, sample_begin=0, seed=5))
+    hi = gpu.render(cam, make_params(72, 40, 14, sample_begin=10, seed=5))
+    assert np.allclose(whole, lo + hi, rtol=1e-5, atol=1e-5)
+    assert not np.array_equal(whole, gpu.render(cam, make_params(72, 40, 24, seed=6)))
+
+
+def test_render_pixel_tile_shards_partition_the_image(gpu, cornell):
+    """Pixel-tile sharding: each 64x64 tile is rendered by exactly one shard, the
+    others leave it zero, and the shards add up to the unsharded image exactly."""
+    gpu.upload_scene(cornell.flat)
+    cam = cornell.camera
+    nx, ny, spp = 200, 136, 8  # ragged: not multiples of 8 or 64
+    whole = gpu.render(cam, make_params(nx, ny, spp, seed=3))
+    parts = [gpu.render(cam, make_params(nx, ny, spp, seed=3, shard_index=k, shard_count=3)) for k in range(3)]
+    assert np.array_equal(whole, parts[0] + parts[1] + parts[2])
+    owner = np.zeros((ny, nx), dtype=int)
+    for k in range(3):
+        lit = parts[k].sum(axis=2) > 0
+        owner[lit] += 1
+        tiles_x = (nx + 63) // 64
+        yy, xx = np.nonzero(lit)
+        assert np.all(((yy // 64) * tiles_x + xx // 64) % 3 == k)
+    assert owner.max() == 1
+
+
+def test_render_matches_oracle_tonemapped(gpu, orc, cornell):
+    """End of the pipe (main.rs:136-155): device tonemap of device sums against
+    the oracle's tonemap of the same sums, and against the oracle's own render on
+    16x16 block means."""
+    gpu.upload_scene(cornell.flat)
+    spp = 64
+    params = make_params(96, 96, spp, seed=31)
+    s = gpu.render(cornell.camera, params)
+    img = gpu.tonemap(s, spp)
+    ref = orc.tonemap(s.astype(np.float64), spp)
+    assert np.abs(img.astype(int) - ref.astype(int)).max() <= 1
+    assert (img != ref).mean() < 0.01
+    os_, _ = orc.render(cornell.flat, cornell.camera.c, make_params(96, 96, spp, seed=32), mode=orc.ORC_F64)
+    oimg = orc.tonemap(os_, spp)
+    blocks = lambda a: a.astype(np.float64).reshape(6, 16, 6, 16, 3).mean(axis=(1, 3))
+    assert np.abs(blocks(img) - blocks(oimg)).max() < 3.0
+
+
+def test_render_argument_errors(gpu, cornell):
+    from raytracing_amd import RtError
+    gpu.upload_scene(cornell.flat)
+    for bad in (make_params(0, 8, 1), make_params(8, 8, 0), make_params(8, 8, 1, shard_index=2, shard_count=2),
+                make_params(8, 8, 1, sky=7)):
+        with pytest.raises(RtError) as e:
+            gpu.render(cornell.camera, bad)
+        assert e.value.code == _lib.RT_ERR_INVALID

@@ -1,0 +1,158 @@
+"""Host-side logic: scene construction, BVH build, flattening, camera, and the
+C ABI surface.  No GPU needed."""
+import ctypes as C
+import math
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+from raytracing_amd import RtError, Scene, _lib
+from raytracing_amd import scene as S
+from raytracing_amd.scenes import cornell_box_scene
+
+
+def test_library_exports_every_declared_symbol():
+    """Every function declared in include/*.h is exported by librt_amd.so."""
+    lib = C.CDLL(_lib.LIB_PATH)
+    names = set()
+    for hdr in ("rt_abi.h", "rt_scene_api.h"):
+        text = open(os.path.join(ROOT, "include", hdr)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        names |= set(re.findall(r"\b(rtb?_[a-z0-9_]+)\s*\(", text))
+    assert len(names) >= 30
+    for n in sorted(names):
+        assert hasattr(lib, n), n
+
+
+def test_struct_sizes_match_the_header():
+    assert C.sizeof(_lib.rt_node) == 32
+    assert C.sizeof(_lib.rt_prim) == 32
+    assert C.sizeof(_lib.rt_object) == 48
+    assert C.sizeof(_lib.rt_material) == 32
+    assert C.sizeof(_lib.rt_texture) == 32
+    assert C.sizeof(_lib.rt_light) == 32
+    assert C.sizeof(_lib.rt_perlin) == 256 * 3 * 4 + 3 * 256 * 4
+
+
+def test_cornell_flattening(cornell):
+    f = cornell.flat
+    # 8 world items -> 15 nodes; 6 wall/light rects + 2 cuboids x 6 rects; 2 instanced objects
+    assert (f.n_nodes, f.n_prims, f.n_objects, f.n_materials, f.n_lights) == (15, 18, 2, 4, 1)
+    leaves = [f.nodes[i] for i in range(f.n_nodes) if f.nodes[i].left < 0]
+    assert len(leaves) == 8
+    assert sorted(n.right for n in leaves) == [0, 0, 1, 1, 1, 1, 1, 1]
+    # breadth-first: children always come later, every node but the root has one parent
+    parents = {}
+    for i in range(f.n_nodes):
+        n = f.nodes[i]
+        if n.left >= 0:
+            assert n.left > i and n.right > i
+            parents.setdefault(n.left, []).append(i)
+            parents.setdefault(n.right, []).append(i)
+    assert sorted(parents) == list(range(1, 15)) and all(len(v) == 1 for v in parents.values())
+    # parent boxes contain child boxes
+    for i in range(f.n_nodes):
+        n = f.nodes[i]
+        if n.left >= 0:
+            for c in (n.left, n.right):
+                ch = f.nodes[c]
+                assert all(n.bmin[k] <= ch.bmin[k] and n.bmax[k] >= ch.bmax[k] for k in range(3))
+    prims = [f.prims[i] for i in range(f.n_prims)]
+    # the left wall keeps the source's z range of 565 (scenes.rs:285) and is flipped
+    left = [p for p in prims if (p.type & 0xFF) == _lib.RT_PRIM_YZ_RECT and p.f[4] == 555.0 and p.f[3] == 565.0]
+    assert len(left) == 1 and (left[0].type & _lib.RT_PRIM_FLIP)
+    # each cuboid is its 6 rects in source order with the top face lifted by 0.01 (hitable.rs:382-415)
+    for oi in range(f.n_objects):
+        ob = f.objects[oi]
+        assert ob.kind == _lib.RT_OBJ_LIST and ob.count == 6
+        assert ob.xform == (_lib.RT_XFORM_ROTATE_Y | _lib.RT_XFORM_TRANSLATE)
+        six = prims[ob.first:ob.first + 6]
+        assert [p.type & 0xFF for p in six] == [1, 1, 2, 2, 3, 3]
+        assert [bool(p.type & _lib.RT_PRIM_FLIP) for p in six] == [False, True, False, True, False, True]
+        height = six[0].f[3]  # y1 of the XY rect
+        assert six[2].f[4] == pytest.approx(height + 0.01, abs=1e-4) and six[2].f[4] > height
+        assert six[3].f[4] == 0.0
+    angles = sorted(math.degrees(math.atan2(f.objects[i].sin_theta, f.objects[i].cos_theta)) for i in range(2))
+    assert angles == pytest.approx([-18.0, 15.0], abs=1e-4)
+
+
+def test_rotate_y_bounding_box_matches_hand_computation():
+    # hitable.rs:477-497 for Cuboid(0, 165) rotated by -18 degrees then translated
+    with Scene(1) as sc:
+        white = S.Lambertian.new_from_color(S.vec3(0.73, 0.73, 0.73))
+        item = S.Translate.new(S.RotateY.new(S.Cuboid.new(S.scalar(0.0), S.scalar(165.0), white), -18.0),
+                               S.vec3(130.0, 0.0, 65.0))
+        flat = sc.flatten(S.HitableList.new([item]))
+        assert flat.n_nodes == 1
+        n = flat.nodes[0]
+        s, c = math.sin(math.radians(-18.0)), math.cos(math.radians(-18.0))
+        xs = [c * x + s * z for x in (0, 165) for z in (0, 165)]
+        zs = [-s * x + c * z for x in (0, 165) for z in (0, 165)]
+        assert n.bmin[0] == pytest.approx(min(xs) + 130, rel=1e-6) and n.bmax[0] == pytest.approx(max(xs) + 130, rel=1e-6)
+        assert n.bmin[2] == pytest.approx(min(zs) + 65, rel=1e-6) and n.bmax[2] == pytest.approx(max(zs) + 65, rel=1e-6)
+        assert (n.bmin[1], n.bmax[1]) == (0.0, 165.0)  # the lifted top face is outside its own box (hitable.rs:375,396)
+
+
+def test_bvh_build_is_seeded_and_median_split():
+    def build(seed, n):
+        with Scene(seed) as sc:
+            m = S.Lambertian.new_from_color(S.vec3(0.5, 0.5, 0.5))
+            rng = np.random.RandomState(5)
+            items = [S.Sphere.new(S.vec3(*rng.uniform(-10, 10, 3)), 0.5, m) for _ in range(n)]
+            f = sc.flatten(S.HitableList.new(items))
+            return [(f.nodes[i].left, f.nodes[i].right, tuple(f.nodes[i].bmin)) for i in range(f.n_nodes)], f.n_prims
+    a, npr = build(3, 37)
+    b, _ = build(3, 37)
+    c, _ = build(4, 37)
+    assert a == b and a != c
+    assert len(a) == 2 * 37 - 1 and npr == 37
+    # one hitable per leaf (bvh.rs:117-125)
+    assert sum(1 for l, r, _ in a if l < 0) == 37 and all(r == 1 for l, r, _ in a if l < 0)
+
+
+def test_camera_matches_camera_rs():
+    cam = S.Camera.new(S.vec3(278, 278, -800), S.vec3(278, 278, 0), S.vec3(0, 1, 0), 40.0, 1.0, 0.0, 10.0).c
+    hh = math.tan(math.radians(40.0) / 2.0)
+    assert list(cam.w) == pytest.approx([0, 0, -1])
+    assert list(cam.u) == pytest.approx([-1, 0, 0])  # vup x w with the sign convention of vec3.rs:180-186
+    assert list(cam.v) == pytest.approx([0, 1, 0])
+    assert list(cam.horizontal) == pytest.approx([-2 * hh * 10, 0, 0])
+    assert list(cam.vertical) == pytest.approx([0, 2 * hh * 10, 0])
+    assert list(cam.lower_left_corner) == pytest.approx([278 + hh * 10, 278 - hh * 10, -790])
+    assert cam.lens_radius == 0.0
+
+
+def test_error_paths():
+    with Scene(1) as sc:
+        m = S.Lambertian.new_from_color(S.vec3(0.5, 0.5, 0.5))
+        sphere = S.Sphere.new(S.vec3(0, 0, 0), 1.0, m)
+        with pytest.raises(RtError) as e:
+            S.FlipNormals.new_xy(sphere)  # hitable.rs:320-325: rects only
+        assert e.value.code == _lib.RT_ERR_INVALID
+        with pytest.raises(RtError):
+            S.BvhNode.new([])
+        # nesting the flattener does not express: RotateY around Translate
+        bad = S.RotateY.new(S.Translate.new(sphere, S.vec3(1, 0, 0)), 10.0)
+        with pytest.raises(RtError) as e:
+            sc.flatten(S.HitableList.new([bad]))
+        assert e.value.code == _lib.RT_ERR_UNSUPPORTED
+        assert b"nesting" in _lib.lib().rt_last_error()
+
+
+def test_perlin_tables_follow_the_degenerate_shuffle():
+    # perlin.rs:81-91: the swap target is always 0, so every permutation is the same fixed rotation
+    with Scene(5) as sc:
+        noise = S.Texture.new_noise(4.0)
+        m = S.Lambertian.new(noise)
+        flat = sc.flatten(S.HitableList.new([S.Sphere.new(S.vec3(0, 0, 0), 1.0, m)]))
+        assert flat.n_perlins == 1
+        p = flat.perlins[0]
+        px, py, pz = list(p.perm_x), list(p.perm_y), list(p.perm_z)
+        assert px == py == pz
+        assert sorted(px) == list(range(256))
+        assert px == [(k + 1) & 255 for k in range(256)]
+        v = np.array([list(p.ranvec[i]) for i in range(256)])
+        assert np.allclose((v ** 2).sum(axis=1), 1.0, atol=1e-6)
