@@ -86,7 +86,7 @@ def test_trace_spheres_and_nested_bvh(gpu, orc):
         d = (tgt - o).astype(np.float32)
         prim, t, normal, p = gpu.trace_closest(o, d, want_normal=True, want_p=True)
         oprim, ot, onormal, op = orc.trace_closest(flat, o, d, mode=orc.ORC_F32_FUSED, want_normal=True, want_p=True)
-        assert (prim >= 0).mean() > 0.9
+        assert (prim >= 0).mean() > 0.6
         assert len(np.unique(prim)) > 60
         assert np.array_equal(prim, oprim), (np.nonzero(prim != oprim)[0][:10])
         assert np.array_equal(t, ot.astype(np.float32))
@@ -97,12 +97,13 @@ def test_trace_spheres_and_nested_bvh(gpu, orc):
 
 
 def test_upload_rejects_malformed_scenes(gpu, cornell):
-    import copy
     import ctypes as C
     from raytracing_amd import RtError, _lib
     flat = cornell.flat
     nodes = (_lib.rt_node * flat.n_nodes)(*[flat.nodes[i] for i in range(flat.n_nodes)])
-    bad = copy.copy(flat)
+    bad = _lib.rt_scene()
+    for name, _ in _lib.rt_scene._fields_:
+        setattr(bad, name, getattr(flat, name))
     bad.nodes = C.cast(nodes, C.POINTER(_lib.rt_node))
     nodes[0].left = 1000  # child index out of range
     with pytest.raises(RtError) as e:
