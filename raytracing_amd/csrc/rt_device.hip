@@ -41,28 +41,47 @@ namespace {
 // ---------------------------------------------------------------------------
 // Device-side scene
 // ---------------------------------------------------------------------------
-enum { SCAN_INTERIOR = 0, SCAN_PRIMS = 1, SCAN_OBJECT = 2 };
+enum {
+  K_INTERIOR = 0,  // box only; children follow
+  K_RECT_XY = 1,   // leaf holding one rect: f = a0,a1,b0,b1,k ; a = prim index
+  K_RECT_XZ = 2,
+  K_RECT_YZ = 3,
+  K_SPHERE = 4,    // leaf holding one sphere: f = cx,cy,cz,r ; a = prim index
+  K_LIST = 5,      // leaf holding prims[a, a+b) as a HitableList in the node's own frame
+  K_OBJ_LIST = 6,  // Translate(RotateY(list)): f = sin,cos,ox,oy,oz ; xform ; prims[a, a+b)
+  K_OBJ_BVH = 7    // Translate(RotateY(BvhNode)): same f/xform; the sub-tree's nodes follow up to skip
+};
 
-// One node of the depth-first ("scan") layout.  Children of an interior node
-// follow it immediately; `skip` is the index of the first node after its subtree.
+// One node of the depth-first ("scan") layout, 64 bytes = one s_load_dwordx16.
+// Children of an interior node follow it immediately; `skip` is the index of the
+// first node after its subtree.  Leaves carry what their test needs inline.
 struct ScanNode {
   float bmin[3];
   int skip;
   float bmax[3];
   int kind;
-  int a;  // SCAN_PRIMS: first prim      SCAN_OBJECT: object index
-  int b;  // SCAN_PRIMS: prim count
-  int pad0, pad1;
+  float f[6];
+  int a;
+  int b;  // prim count; for K_OBJ_*: count | xform << 24
 };
+
+// Scene buffers are written by rt_upload_scene and only read by kernels, so
+// wave-uniform reads go through the constant address space: that is what makes
+// the compiler emit scalar loads (s_load_dwordx16 into SGPRs) for them.
+#define RT_CONSTANT_AS __attribute__((address_space(4)))
+typedef unsigned u32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x8 __attribute__((ext_vector_type(8)));
 
 struct DevScene {
   const ScanNode* scan;
   const rt_prim* prims;
+  const int* prim_obj;  // object whose frame a primitive lives in, -1 = world frame
   const rt_object* objects;
   const rt_material* materials;
   const rt_texture* textures;
   const rt_perlin* perlins;
   int n_scan, n_prims, n_objects, n_lights;
+  int flat;  // 1: the scan array holds leaves only (every skip is the next index)
   rt_light light;
 };
 
@@ -75,15 +94,9 @@ struct F3 {
   float x, y, z;
 };
 __device__ __forceinline__ F3 f3(float x, float y, float z) { F3 r; r.x = x; r.y = y; r.z = z; return r; }
-__device__ __forceinline__ F3 operator+(F3 a, F3 b) { return f3(a.x + b.x, a.y + b.y, a.z + b.z); }
-__device__ __forceinline__ F3 operator-(F3 a, F3 b) { return f3(a.x - b.x, a.y - b.y, a.z - b.z); }
 __device__ __forceinline__ F3 operator*(F3 a, float s) { return f3(a.x * s, a.y * s, a.z * s); }
 // z*z' + (y*y' + x*x') with single-rounding multiply-adds (the oracle's fused dot).
 __device__ __forceinline__ float dot3(F3 a, F3 b) { return fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x)); }
-__device__ __forceinline__ F3 cross3(F3 a, F3 b) {  // vec3.rs:180-186
-  return f3(a.y * b.z - a.z * b.y, -(a.x * b.z - a.z * b.x), a.x * b.y - a.y * b.x);
-}
-__device__ __forceinline__ F3 unit3(F3 a) { return a * (1.0f / sqrtf(dot3(a, a))); }  // vec3.rs:188-190
 
 struct RayF {
   F3 o, d, inv;
@@ -97,7 +110,9 @@ __device__ __forceinline__ RayF make_ray(F3 o, F3 d) {
 }
 
 // Translate::hit (hitable.rs:440) then RotateY::hit (hitable.rs:510-518): the ray
-// in the object's frame.  d.y, and so inv.y, is unchanged.
+// in the object's frame.  d.y, and so inv.y, is unchanged.  WANT_INV = false
+// skips the two reciprocals (the caller only needs o and d).
+template <bool WANT_INV>
 __device__ __forceinline__ RayF to_object_frame(const RayF& w, int xform, float sin_t, float cos_t, float ox, float oy, float oz) {
   RayF r = w;
   if (xform & RT_XFORM_TRANSLATE) r.o = f3(w.o.x - ox, w.o.y - oy, w.o.z - oz);
@@ -107,70 +122,92 @@ __device__ __forceinline__ RayF to_object_frame(const RayF& w, int xform, float 
     r.o.z = fmaf(sin_t, o.x, cos_t * o.z);
     r.d.x = fmaf(cos_t, d.x, -(sin_t * d.z));
     r.d.z = fmaf(sin_t, d.x, cos_t * d.z);
-    r.inv.x = 1.0f / r.d.x;
-    r.inv.z = 1.0f / r.d.z;
+    if (WANT_INV) {
+      r.inv.x = 1.0f / r.d.x;
+      r.inv.z = 1.0f / r.d.z;
+    }
   }
   return r;
 }
 
+__device__ __forceinline__ ScanNode load_node(const ScanNode* base, int i) {
+  const u32x16 v = *(const RT_CONSTANT_AS u32x16*)(base + i);
+  ScanNode n;
+  __builtin_memcpy(&n, &v, sizeof(n));
+  return n;
+}
+__device__ __forceinline__ rt_prim load_prim_uniform(const rt_prim* base, int i) {
+  const u32x8 v = *(const RT_CONSTANT_AS u32x8*)(base + i);
+  rt_prim q;
+  __builtin_memcpy(&q, &v, sizeof(q));
+  return q;
+}
+
 struct Counters {
-  unsigned long long rays, hits, node_tests, rect_tests, sphere_tests, instance_ops, shade_events, light_tests, paths;
+  unsigned rays, hits, node_tests, rect_tests, sphere_tests, instance_ops, shade_events, light_tests, paths;
 };
 
 struct Hit {
   float t;
   int prim;  // index into prims, -1 = none
-  int obj;   // object whose frame the hit was found in, -1 = world frame
 };
 
 // Aabb::hit (bvh.rs:46-61) with the reference's comparisons: a NaN slab value
 // leaves the interval unchanged (v_max/v_min return the other operand), a
 // negative reciprocal swaps the pair, an empty or zero-width interval misses.
 // The three per-axis exits of the source collapse into one test because the
-// interval only ever shrinks.  Returns the entry parameter through t_enter.
-__device__ __forceinline__ bool slab_test(const ScanNode& n, const RayF& r, float t_min, float t_max, float& t_enter) {
+// interval only ever shrinks.  `best_t` adds the pruning test: a box entered
+// beyond the best hit so far cannot hold the winner.
+struct Signs {
+  bool x, y, z;  // reciprocal direction negative, per axis
+};
+__device__ __forceinline__ Signs ray_signs(const RayF& r) {
+  Signs s;
+  s.x = r.inv.x < 0.0f;
+  s.y = r.inv.y < 0.0f;
+  s.z = r.inv.z < 0.0f;
+  return s;
+}
+__device__ __forceinline__ bool slab_test(const ScanNode& n, const RayF& r, const Signs& sg, float t_min, float t_max, float best_t) {
   float t0 = (n.bmin[0] - r.o.x) * r.inv.x, t1 = (n.bmax[0] - r.o.x) * r.inv.x;
-  float lo = r.inv.x < 0.0f ? t1 : t0, hi = r.inv.x < 0.0f ? t0 : t1;
-  t_min = fmaxf(lo, t_min);
-  t_max = fminf(hi, t_max);
+  t_min = fmaxf(sg.x ? t1 : t0, t_min);
+  t_max = fminf(sg.x ? t0 : t1, t_max);
   t0 = (n.bmin[1] - r.o.y) * r.inv.y; t1 = (n.bmax[1] - r.o.y) * r.inv.y;
-  lo = r.inv.y < 0.0f ? t1 : t0; hi = r.inv.y < 0.0f ? t0 : t1;
-  t_min = fmaxf(lo, t_min);
-  t_max = fminf(hi, t_max);
+  t_min = fmaxf(sg.y ? t1 : t0, t_min);
+  t_max = fminf(sg.y ? t0 : t1, t_max);
   t0 = (n.bmin[2] - r.o.z) * r.inv.z; t1 = (n.bmax[2] - r.o.z) * r.inv.z;
-  lo = r.inv.z < 0.0f ? t1 : t0; hi = r.inv.z < 0.0f ? t0 : t1;
-  t_min = fmaxf(lo, t_min);
-  t_max = fminf(hi, t_max);
-  t_enter = t_min;
-  return !(t_max <= t_min);
+  t_min = fmaxf(sg.z ? t1 : t0, t_min);
+  t_max = fminf(sg.z ? t0 : t1, t_max);
+  return !(t_max <= t_min) & !(t_min > best_t);
 }
 
 // XYRect/XZRect/YZRect::hit (hitable.rs:163-173 and twins).  C is the fixed
-// axis, A and B the in-plane axes in constructor order.  The source's rejects
-// are written as negated comparisons so a NaN passes them exactly as it does
+// axis, A and B the in-plane axes in constructor order; f = a0,a1,b0,b1,k.  The
+// source's rejects are kept as written so a NaN passes them exactly as it does
 // there.  t = (k - o[C]) * (1/d[C]) replaces the source's division.
 template <int C, int A, int B>
-__device__ __forceinline__ bool rect_test(const rt_prim& q, const RayF& r, float t0, float t1, float& t_out) {
+__device__ __forceinline__ bool rect_test(const float* f, const RayF& r, float t0, float t1, float& t_out) {
   const float oc = C == 0 ? r.o.x : (C == 1 ? r.o.y : r.o.z);
   const float ic = C == 0 ? r.inv.x : (C == 1 ? r.inv.y : r.inv.z);
   const float oa = A == 0 ? r.o.x : (A == 1 ? r.o.y : r.o.z);
   const float da = A == 0 ? r.d.x : (A == 1 ? r.d.y : r.d.z);
   const float ob = B == 0 ? r.o.x : (B == 1 ? r.o.y : r.o.z);
   const float db = B == 0 ? r.d.x : (B == 1 ? r.d.y : r.d.z);
-  const float t = (q.f[4] - oc) * ic;
+  const float t = (f[4] - oc) * ic;
   const float a = fmaf(t, da, oa);
   const float b = fmaf(t, db, ob);
-  const bool miss = (t < t0) | (t > t1) | (a < q.f[0]) | (a > q.f[1]) | (b < q.f[2]) | (b > q.f[3]);
+  const bool miss = (t < t0) | (t > t1) | (a < f[0]) | (a > f[1]) | (b < f[2]) | (b > f[3]);
   t_out = t;
   return !miss;
 }
 
-// Sphere::hit (hitable.rs:50-82): half-b quadratic, nearer root first, strict bounds.
-__device__ __forceinline__ bool sphere_test(const rt_prim& q, const RayF& r, float t_min, float t_max, float& t_out) {
-  const F3 oc = f3(r.o.x - q.f[0], r.o.y - q.f[1], r.o.z - q.f[2]);
+// Sphere::hit (hitable.rs:50-82): half-b quadratic, nearer root first, strict
+// bounds; f = cx,cy,cz,r.
+__device__ __forceinline__ bool sphere_test(const float* f, const RayF& r, float t_min, float t_max, float& t_out) {
+  const F3 oc = f3(r.o.x - f[0], r.o.y - f[1], r.o.z - f[2]);
   const float a = dot3(r.d, r.d);
   const float b = dot3(oc, r.d);
-  const float c = fmaf(-q.f[3], q.f[3], dot3(oc, oc));
+  const float c = fmaf(-f[3], f[3], dot3(oc, oc));
   const float disc = fmaf(b, b, -(a * c));
   bool hit = false;
   if (disc > 0.0f) {
@@ -190,23 +227,24 @@ __device__ __forceinline__ bool sphere_test(const rt_prim& q, const RayF& r, flo
 
 // HitableList::hit (hitable.rs:105-117) over prims[first, first+count) with a
 // wave-uniform loop, so the primitive records are scalar loads.  The list's own
-// closest_so_far starts at t_max; the winner then meets the running best under
-// the BVH's tie rule.
+// closest_so_far starts at t_max; its winner then meets the running best under
+// BvhNode::hit's rule (bvh.rs:212-217): the earlier hit survives only if it is
+// strictly nearer.
 template <bool STATS>
-__device__ __forceinline__ void list_test(const DevScene& S, int first, int count, int obj, bool lane_on, const RayF& r,
+__device__ __forceinline__ void list_test(const rt_prim* __restrict__ prims, int first, int count, bool lane_on, const RayF& r,
                                           float t_min, float t_max, Hit& best, Counters& cnt) {
   float loc_t = t_max;
   int loc_prim = -1;
   for (int qi = first; qi < first + count; ++qi) {
-    const rt_prim q = S.prims[qi];
+    const rt_prim q = load_prim_uniform(prims, __builtin_amdgcn_readfirstlane(qi));
     const int type = q.type & RT_PRIM_TYPE_MASK;
     float t = 0.0f;
     bool h = false;
     if (lane_on) {
-      if (type == RT_PRIM_XY_RECT) h = rect_test<2, 0, 1>(q, r, t_min, loc_t, t);
-      else if (type == RT_PRIM_XZ_RECT) h = rect_test<1, 0, 2>(q, r, t_min, loc_t, t);
-      else if (type == RT_PRIM_YZ_RECT) h = rect_test<0, 1, 2>(q, r, t_min, loc_t, t);
-      else h = sphere_test(q, r, t_min, loc_t, t);
+      if (type == RT_PRIM_XY_RECT) h = rect_test<2, 0, 1>(q.f, r, t_min, loc_t, t);
+      else if (type == RT_PRIM_XZ_RECT) h = rect_test<1, 0, 2>(q.f, r, t_min, loc_t, t);
+      else if (type == RT_PRIM_YZ_RECT) h = rect_test<0, 1, 2>(q.f, r, t_min, loc_t, t);
+      else h = sphere_test(q.f, r, t_min, loc_t, t);
       if (STATS) {
         if (type == RT_PRIM_SPHERE) cnt.sphere_tests++;
         else cnt.rect_tests++;
@@ -217,11 +255,9 @@ __device__ __forceinline__ void list_test(const DevScene& S, int first, int coun
       loc_prim = qi;
     }
   }
-  // bvh.rs:212-217: the earlier hit survives only if it is strictly nearer.
-  if (loc_prim >= 0 && !(best.prim >= 0 && best.t < loc_t)) {
+  if (loc_prim >= 0 && !(best.t < loc_t)) {
     best.t = loc_t;
     best.prim = loc_prim;
-    best.obj = obj;
   }
 }
 
@@ -230,63 +266,91 @@ __device__ __forceinline__ int wave_min_i32(int v) {
   return v;
 }
 
-// Nearest hit of BvhNode::hit (bvh.rs:197-228) over the scan layout.  Must be
-// called by all 64 lanes of the wave; lanes with active == false take no part.
-// Pruning: a node is also skipped when its entry parameter lies beyond the best
-// hit so far, which cannot change the winner.
+// Walks scan[begin, end) for the lanes with active == true, all 64 lanes of the
+// wave taking part in the control flow.  LEVEL 0 is the world frame; a K_OBJ_BVH
+// node re-enters at LEVEL 1 with the ray moved into the object's frame.  FLAT
+// means every node is a leaf, so no lane ever skips ahead.
+template <bool STATS, bool FLAT, int LEVEL>
+__device__ __forceinline__ void scan_range(const DevScene& S, int begin, int end, bool active, const RayF& r, float t_min, float t_max,
+                                           Hit& best, Counters& cnt) {
+  const Signs sg = ray_signs(r);
+  int lane_next = active ? begin : 0x7fffffff;
+  int i = begin;
+  while (i < end) {
+    bool act = active;
+    if (!FLAT) {
+      act = lane_next <= i;
+      if (__ballot(act) == 0ull) {
+        i = __builtin_amdgcn_readfirstlane(min(wave_min_i32(lane_next), end));
+        continue;
+      }
+    }
+    // readfirstlane pins the index to an SGPR so the node arrives by scalar load.
+    i = __builtin_amdgcn_readfirstlane(i);
+    const ScanNode n = load_node(S.scan, i);
+    bool on = false;
+    if (act) {
+      on = slab_test(n, r, sg, t_min, t_max, best.t);
+      if (STATS) cnt.node_tests++;
+      if (!FLAT && !on) lane_next = n.skip;
+    }
+    const int kind = n.kind;
+    if (kind >= K_RECT_XY && kind <= K_RECT_YZ) {
+      // A single rect: its own t_max test against the running best is the tie rule.
+      float t = 0.0f;
+      bool h = false;
+      if (on) {
+        if (kind == K_RECT_XY) h = rect_test<2, 0, 1>(n.f, r, t_min, best.t, t);
+        else if (kind == K_RECT_XZ) h = rect_test<1, 0, 2>(n.f, r, t_min, best.t, t);
+        else h = rect_test<0, 1, 2>(n.f, r, t_min, best.t, t);
+        if (STATS) cnt.rect_tests++;
+      }
+      if (h) {
+        best.t = t;
+        best.prim = n.a;
+      }
+    } else if (kind == K_SPHERE) {
+      float t = 0.0f;
+      bool h = false;
+      if (on) {
+        h = sphere_test(n.f, r, t_min, t_max, t);
+        if (STATS) cnt.sphere_tests++;
+      }
+      if (h && !(best.t < t)) {
+        best.t = t;
+        best.prim = n.a;
+      }
+    } else if (kind == K_LIST) {
+      if (__ballot(on) != 0ull) list_test<STATS>(S.prims, n.a, n.b, on, r, t_min, t_max, best, cnt);
+    } else if (kind == K_OBJ_LIST || kind == K_OBJ_BVH) {
+      if (LEVEL == 0) {
+        if (__ballot(on) != 0ull) {
+          RayF q = r;
+          if (on) {
+            q = to_object_frame<true>(r, n.b >> 24, n.f[0], n.f[1], n.f[2], n.f[3], n.f[4]);
+            if (STATS) cnt.instance_ops++;
+          }
+          if (kind == K_OBJ_LIST) list_test<STATS>(S.prims, n.a, n.b & 0xffffff, on, q, t_min, t_max, best, cnt);
+          else scan_range<STATS, false, 1>(S, i + 1, n.skip, on, q, t_min, t_max, best, cnt);
+        }
+        if (kind == K_OBJ_BVH) {
+          i = n.skip;
+          continue;
+        }
+      }
+    }
+    ++i;
+  }
+}
+
+// Nearest hit of BvhNode::hit (bvh.rs:197-228).  Must be called by all 64 lanes.
 template <bool STATS>
 __device__ __forceinline__ Hit trace_scan(const DevScene& S, bool active, const RayF& w, float t_min, float t_max, Counters& cnt) {
   Hit best;
   best.t = t_max;
   best.prim = -1;
-  best.obj = -1;
-  int lane_next = active ? 0 : 0x7fffffff;
-  RayF loc = w;      // ray in the frame of the sub-tree being walked
-  int inst_end = -1;  // scan index at which that sub-tree ends
-  int inst_obj = -1;
-  int i = 0;
-  const int n_scan = S.n_scan;
-  while (i < n_scan) {
-    i = __builtin_amdgcn_readfirstlane(i);
-    if (i >= inst_end) inst_obj = -1;
-    const bool act = lane_next <= i;
-    if (__ballot(act) == 0ull) {
-      i = wave_min_i32(lane_next);
-      continue;
-    }
-    const ScanNode n = S.scan[i];
-    const bool inside = inst_obj >= 0;
-    bool on = false;
-    if (act) {
-      float t_enter;
-      on = slab_test(n, inside ? loc : w, t_min, t_max, t_enter);
-      if (STATS) cnt.node_tests++;
-      on = on && !(t_enter > best.t);
-      if (!on) lane_next = n.skip;
-    }
-    if (n.kind == SCAN_PRIMS) {
-      if (__ballot(on) != 0ull) list_test<STATS>(S, n.a, n.b, inst_obj, on, inside ? loc : w, t_min, t_max, best, cnt);
-    } else if (n.kind == SCAN_OBJECT) {
-      const rt_object ob = S.objects[n.a];
-      if (ob.kind == RT_OBJ_LIST) {
-        if (__ballot(on) != 0ull) {
-          const RayF r = to_object_frame(w, ob.xform, ob.sin_theta, ob.cos_theta, ob.offset[0], ob.offset[1], ob.offset[2]);
-          if (STATS && on) cnt.instance_ops++;
-          list_test<STATS>(S, ob.first, ob.count, n.a, on, r, t_min, t_max, best, cnt);
-        }
-      } else if (ob.kind == RT_OBJ_BVH) {
-        // The sub-tree's nodes follow inline up to n.skip; lanes that missed the
-        // box already point past it.
-        if (on) loc = to_object_frame(w, ob.xform, ob.sin_theta, ob.cos_theta, ob.offset[0], ob.offset[1], ob.offset[2]);
-        if (STATS && on) cnt.instance_ops++;
-        inst_obj = n.a;
-        inst_end = n.skip;
-      }
-      // RT_OBJ_MEDIUM takes random numbers: the render kernel handles it, a
-      // deterministic query skips it.
-    }
-    ++i;
-  }
+  if (S.flat) scan_range<STATS, true, 0>(S, 0, S.n_scan, active, w, t_min, t_max, best, cnt);
+  else scan_range<STATS, false, 0>(S, 0, S.n_scan, active, w, t_min, t_max, best, cnt);
   return best;
 }
 
@@ -301,14 +365,15 @@ struct Surface {
 __device__ __forceinline__ Surface finalize_hit(const DevScene& S, const RayF& w, const Hit& h) {
   Surface s;
   const rt_prim q = S.prims[h.prim];
+  const int obj = S.prim_obj[h.prim];
   RayF r = w;
   int xform = 0;
   float sin_t = 0.0f, cos_t = 1.0f, ox = 0.0f, oy = 0.0f, oz = 0.0f;
-  if (h.obj >= 0) {
-    const rt_object ob = S.objects[h.obj];
+  if (obj >= 0) {
+    const rt_object ob = S.objects[obj];
     xform = ob.xform; sin_t = ob.sin_theta; cos_t = ob.cos_theta;
     ox = ob.offset[0]; oy = ob.offset[1]; oz = ob.offset[2];
-    r = to_object_frame(w, xform, sin_t, cos_t, ox, oy, oz);
+    r = to_object_frame<false>(w, xform, sin_t, cos_t, ox, oy, oz);
   }
   F3 p = f3(fmaf(h.t, r.d.x, r.o.x), fmaf(h.t, r.d.y, r.o.y), fmaf(h.t, r.d.z, r.o.z));
   F3 nrm;
@@ -391,6 +456,17 @@ __device__ __forceinline__ U4 philox4x32_10(unsigned c0, unsigned c1, unsigned c
 }
 __device__ __forceinline__ float u01(unsigned x) { return (float)(x >> 8) * (1.0f / 16777216.0f); }
 
+// Shading-side helpers.  Nothing from here on is compared bit for bit with the
+// CPU (Monte Carlo sums are checked statistically), so the hardware's 1-ulp
+// reciprocal, reciprocal square root and square root are used directly.
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float fast_rsq(float x) { return __builtin_amdgcn_rsqf(x); }
+__device__ __forceinline__ float fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+__device__ __forceinline__ F3 cross3(F3 a, F3 b) {  // vec3.rs:180-186
+  return f3(fmaf(a.y, b.z, -(a.z * b.y)), fmaf(a.z, b.x, -(a.x * b.z)), fmaf(a.x, b.y, -(a.y * b.x)));
+}
+__device__ __forceinline__ F3 unit3(F3 a) { return a * fast_rsq(dot3(a, a)); }  // vec3.rs:188-190
+
 // Texture::value (texture.rs:22-35).  This build evaluates constant textures.
 __device__ __forceinline__ F3 texture_value(const DevScene& S, int tex, F3 p) {
   const rt_texture t = S.textures[tex];
@@ -399,13 +475,13 @@ __device__ __forceinline__ F3 texture_value(const DevScene& S, int tex, F3 p) {
 
 struct RenderArgs {
   int nx, ny, spp, sample_begin, max_depth, sky;
-  float t_min;
+  float t_min, inv_nx, inv_ny;
   int shard_index, shard_count;
   unsigned key0, key1;
   int tiles_x, tiles_y;
 };
 
-#define RT_PI_F 3.14159265358979323846f
+#define RT_INV_PI_F 0.31830988618379067154f
 
 // ---------------------------------------------------------------------------
 // render_kernel
@@ -413,7 +489,7 @@ struct RenderArgs {
 template <bool STATS, bool SUMSQ>
 __global__ void __launch_bounds__(256) render_kernel(DevScene S, DevCamera cam, RenderArgs A, float* __restrict__ out_sum,
                                                      float* __restrict__ out_sumsq, unsigned long long* __restrict__ stats) {
-  __shared__ float acc[4][SUMSQ ? 6 : 3][64];
+  __shared__ float acc[4][6][64];
   const int lane = threadIdx.x & 63;
   const int wib = threadIdx.x >> 6;
   const int tile = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wib);
@@ -458,8 +534,8 @@ __global__ void __launch_bounds__(256) render_kernel(DevScene S, DevCamera cam, 
           pixel_id = (unsigned)(j * A.nx + px);
           sample = (unsigned)(A.sample_begin + s);
           U4 w = philox4x32_10(pixel_id, sample, 0u, 0u, A.key0, A.key1);
-          const float u = ((float)px + u01(w.x)) / (float)A.nx;
-          const float v = ((float)j + u01(w.y)) / (float)A.ny;
+          const float u = ((float)px + u01(w.x)) * A.inv_nx;
+          const float v = ((float)j + u01(w.y)) * A.inv_ny;
           // camera.rs:53-75
           float rdx = 0.0f, rdy = 0.0f;
           if (cam.lens_radius != 0.0f) {
@@ -533,35 +609,35 @@ __global__ void __launch_bounds__(256) render_kernel(DevScene S, DevCamera cam, 
           } else {
             // random_cosine_direction, main.rs:239-249 (x and y keep the source's factor 2);
             // v_sin/v_cos take their argument in turns, so phi = 2*pi*r1 is r1 turns.
-            const float z = sqrtf(1.0f - xi2);
-            const float r2s = 2.0f * sqrtf(xi2);
+            const float z = fast_sqrt(1.0f - xi2);
+            const float r2s = 2.0f * fast_sqrt(xi2);
             const float x = __builtin_amdgcn_cosf(xi1) * r2s;
             const float y = __builtin_amdgcn_sinf(xi1) * r2s;
             dir = f3(fmaf(z, ww.x, fmaf(y, vv.x, x * uu.x)), fmaf(z, ww.y, fmaf(y, vv.y, x * uu.y)), fmaf(z, ww.z, fmaf(y, vv.z, x * uu.z)));
           }
           const float dlen2 = dot3(dir, dir);
-          const float inv_len = 1.0f / sqrtf(dlen2);
+          const float inv_len = fast_rsq(dlen2);
           // pdf.rs:19-26
           const float cos_w = dot3(dir, ww) * inv_len;
-          float pdf_val = cos_w > 0.0f ? cos_w * (1.0f / RT_PI_F) : 0.0f;
+          float pdf_val = cos_w > 0.0f ? cos_w * RT_INV_PI_F : 0.0f;
           if (S.n_lights > 0) {
             // XZRect::pdf_value, hitable.rs:245-254 (its hit test uses 0.001 and f64::MAX)
             if (STATS) cnt.light_tests++;
             float lp = 0.0f;
-            const float t = (S.light.f[4] - sf.p.y) / dir.y;
+            const float t = (S.light.f[4] - sf.p.y) * fast_rcp(dir.y);
             const float lx = fmaf(t, dir.x, sf.p.x), lz = fmaf(t, dir.z, sf.p.z);
             const bool miss = (t < 0.001f) | (t > 3.402823466e+38f) | (lx < S.light.f[0]) | (lx > S.light.f[1]) | (lz < S.light.f[2]) | (lz > S.light.f[3]);
             if (!miss) {
               const float area = (S.light.f[1] - S.light.f[0]) * (S.light.f[3] - S.light.f[2]);
               const float cosine = fabsf(dir.y * inv_len);
-              lp = (t * t * dlen2) / (cosine * area);
+              lp = (t * t * dlen2) * fast_rcp(cosine * area);
             }
             pdf_val = 0.5f * lp + 0.5f * pdf_val;
           }
           // material.rs:76-82
           float cos_n = dot3(sf.normal, dir) * inv_len;
           if (cos_n < 0.0f) cos_n = 0.0f;
-          const float f = (cos_n * (1.0f / RT_PI_F)) / pdf_val;
+          const float f = (cos_n * RT_INV_PI_F) * fast_rcp(pdf_val);
           thr = f3(thr.x * albedo.x * f, thr.y * albedo.y * f, thr.z * albedo.z * f);
           // A zero or NaN weight fixes the sample's value (0 after de_nan) whatever
           // the rest of the path does, so the path ends here.
@@ -610,7 +686,7 @@ __global__ void __launch_bounds__(256) render_kernel(DevScene S, DevCamera cam, 
     }
   }
   if (STATS) {
-    unsigned long long v[9] = {cnt.paths, cnt.rays, cnt.hits, cnt.node_tests, cnt.rect_tests, cnt.sphere_tests, cnt.instance_ops, cnt.shade_events, cnt.light_tests};
+    const unsigned v[9] = {cnt.paths, cnt.rays, cnt.hits, cnt.node_tests, cnt.rect_tests, cnt.sphere_tests, cnt.instance_ops, cnt.shade_events, cnt.light_tests};
 #pragma unroll
     for (int k = 0; k < 9; ++k) {
       unsigned long long x = v[k];
@@ -646,6 +722,7 @@ struct rt_ctx {
   DevScene dev;
   void* d_scan;
   void* d_prims;
+  void* d_prim_obj;
   void* d_objects;
   void* d_materials;
   void* d_textures;
@@ -667,7 +744,7 @@ int hip_fail(hipError_t e, const char* what) {
   } while (0)
 
 void free_scene(rt_ctx* ctx) {
-  void** ptrs[] = {&ctx->d_scan, &ctx->d_prims, &ctx->d_objects, &ctx->d_materials, &ctx->d_textures, &ctx->d_perlins};
+  void** ptrs[] = {&ctx->d_scan, &ctx->d_prims, &ctx->d_prim_obj, &ctx->d_objects, &ctx->d_materials, &ctx->d_textures, &ctx->d_perlins};
   for (size_t i = 0; i < sizeof(ptrs) / sizeof(ptrs[0]); ++i) {
     if (*ptrs[i]) (void)hipFree(*ptrs[i]);
     *ptrs[i] = nullptr;
@@ -716,46 +793,122 @@ int validate_scene(const rt_scene* s) {
   return RT_OK;
 }
 
-// Depth-first re-layout of the breadth-first node array.  `in_sub` marks nodes
-// of a BvhNode used as a child hitable, whose leaves must be primitive leaves.
-int build_scan(const rt_scene* s, int idx, bool in_sub, int depth, std::vector<ScanNode>* out) {
+// Leaves under each node of the breadth-first array, with the structural checks
+// (indices in range, no cycles) done on the way.
+int count_leaves(const rt_scene* s, int idx, int depth, std::vector<int>* memo) {
   if (idx < 0 || idx >= s->n_nodes) return rt::set_error(RT_ERR_INVALID, "node index out of range");
   if (depth > 64) return rt::set_error(RT_ERR_INVALID, "node tree deeper than 64 levels (cycle?)");
-  if ((int)out->size() > 4 * s->n_nodes + 16) return rt::set_error(RT_ERR_INVALID, "node array is not a tree");
+  if ((*memo)[idx] > 0) return rt::set_error(RT_ERR_INVALID, "node array is not a tree (a node has two parents)");
   const rt_node& n = s->nodes[idx];
-  const size_t at = out->size();
+  int leaves = 1;
+  if (n.left >= 0) {
+    if (n.right < 0) return rt::set_error(RT_ERR_INVALID, "interior node with a negative right child");
+    const int a = count_leaves(s, n.left, depth + 1, memo);
+    if (a < 0) return a;
+    const int b = count_leaves(s, n.right, depth + 1, memo);
+    if (b < 0) return b;
+    leaves = a + b;
+  }
+  (*memo)[idx] = leaves;
+  return leaves;
+}
+
+// Sub-trees with at most this many leaves are stored as their leaves alone.  A
+// leaf's box lies inside every ancestor's box and the slab arithmetic is
+// monotonic in the box bounds, so a ray that passes the leaf's Aabb::hit passes
+// every ancestor's: dropping the interior tests changes no result, and for a
+// handful of leaves a wave of 64 incoherent rays would have visited them all anyway.
+const int kTreeletLeaves = 16;
+
+struct ScanBuilder {
+  const rt_scene* s;
+  std::vector<int> leaves;
+  std::vector<ScanNode> out;
+  std::vector<int> prim_obj;
+  bool any_interior;
+};
+
+ScanNode box_node(const rt_node& n) {
   ScanNode sn;
   std::memset(&sn, 0, sizeof(sn));
   for (int c = 0; c < 3; ++c) { sn.bmin[c] = n.bmin[c]; sn.bmax[c] = n.bmax[c]; }
-  out->push_back(sn);
-  if (n.left < 0) {
-    const int ref = ~n.left;
-    if (n.right > 0) {
-      if (ref < 0 || ref + n.right > s->n_prims) return rt::set_error(RT_ERR_INVALID, "leaf primitive range out of bounds");
-      (*out)[at].kind = SCAN_PRIMS;
-      (*out)[at].a = ref;
-      (*out)[at].b = n.right;
-    } else if (n.right == 0) {
-      if (in_sub) return rt::set_error(RT_ERR_UNSUPPORTED, "objects inside an object's sub-tree are not supported");
-      if (ref < 0 || ref >= s->n_objects) return rt::set_error(RT_ERR_INVALID, "leaf object index out of range");
-      (*out)[at].kind = SCAN_OBJECT;
-      (*out)[at].a = ref;
-      if (s->objects[ref].kind == RT_OBJ_BVH) {
-        const int rc = build_scan(s, s->objects[ref].first, true, depth + 1, out);
-        if (rc != RT_OK) return rc;
-      }
-    } else {
-      return rt::set_error(RT_ERR_INVALID, "leaf with negative count");
+  return sn;
+}
+
+// Depth-first re-layout of the breadth-first node array.  `in_sub` marks nodes
+// of a BvhNode used as a child hitable, whose leaves must be primitive leaves;
+// `collapsed` is true below the root of a treelet stored as leaves only.
+int build_scan(ScanBuilder* B, int idx, bool in_sub, bool collapsed, bool tree_root, int obj) {
+  const rt_scene* s = B->s;
+  const rt_node& n = s->nodes[idx];
+  if (n.left >= 0) {
+    const bool small = B->leaves[idx] <= kTreeletLeaves;
+    const bool emit = !collapsed && !(small && tree_root);
+    const size_t at = B->out.size();
+    if (emit) {
+      ScanNode sn = box_node(n);
+      sn.kind = K_INTERIOR;
+      B->out.push_back(sn);
+      B->any_interior = true;
     }
-  } else {
-    if (n.right < 0) return rt::set_error(RT_ERR_INVALID, "interior node with a negative right child");
-    (*out)[at].kind = SCAN_INTERIOR;
-    int rc = build_scan(s, n.left, in_sub, depth + 1, out);
+    int rc = build_scan(B, n.left, in_sub, collapsed || small, false, obj);
     if (rc != RT_OK) return rc;
-    rc = build_scan(s, n.right, in_sub, depth + 1, out);
+    rc = build_scan(B, n.right, in_sub, collapsed || small, false, obj);
     if (rc != RT_OK) return rc;
+    if (emit) B->out[at].skip = (int)B->out.size();
+    return RT_OK;
   }
-  (*out)[at].skip = (int)out->size();
+  ScanNode sn = box_node(n);
+  const int ref = ~n.left;
+  if (n.right > 0) {
+    if (ref < 0 || ref + n.right > s->n_prims) return rt::set_error(RT_ERR_INVALID, "leaf primitive range out of bounds");
+    for (int k = ref; k < ref + n.right; ++k) B->prim_obj[k] = obj;
+    if (n.right == 1) {
+      const rt_prim& q = s->prims[ref];
+      const int type = q.type & RT_PRIM_TYPE_MASK;
+      sn.kind = type == RT_PRIM_SPHERE ? K_SPHERE : (type == RT_PRIM_XY_RECT ? K_RECT_XY : (type == RT_PRIM_XZ_RECT ? K_RECT_XZ : K_RECT_YZ));
+      for (int k = 0; k < 6; ++k) sn.f[k] = q.f[k];
+      sn.a = ref;
+      sn.b = 1;
+    } else {
+      sn.kind = K_LIST;
+      sn.a = ref;
+      sn.b = n.right;
+    }
+    sn.skip = (int)B->out.size() + 1;
+    B->out.push_back(sn);
+    return RT_OK;
+  }
+  if (n.right < 0) return rt::set_error(RT_ERR_INVALID, "leaf with negative count");
+  if (in_sub) return rt::set_error(RT_ERR_UNSUPPORTED, "objects inside an object's sub-tree are not supported");
+  if (ref < 0 || ref >= s->n_objects) return rt::set_error(RT_ERR_INVALID, "leaf object index out of range");
+  const rt_object& ob = s->objects[ref];
+  sn.f[0] = ob.sin_theta; sn.f[1] = ob.cos_theta;
+  sn.f[2] = ob.offset[0]; sn.f[3] = ob.offset[1]; sn.f[4] = ob.offset[2];
+  const size_t at = B->out.size();
+  if (ob.kind == RT_OBJ_LIST) {
+    for (int k = ob.first; k < ob.first + ob.count; ++k) B->prim_obj[k] = ref;
+    sn.kind = K_OBJ_LIST;
+    sn.a = ob.first;
+    sn.b = ob.count | (ob.xform << 24);
+    sn.skip = (int)at + 1;
+    B->out.push_back(sn);
+    return RT_OK;
+  }
+  // RT_OBJ_BVH: the sub-tree follows inline, in the object's frame.
+  sn.kind = K_OBJ_BVH;
+  sn.b = ob.xform << 24;
+  B->out.push_back(sn);
+  B->any_interior = true;
+  if (B->leaves[ob.first] == 0) {
+    const int rc = count_leaves(s, ob.first, 0, &B->leaves);
+    if (rc < 0) return rc;
+  } else {
+    return rt::set_error(RT_ERR_INVALID, "object sub-tree is shared with another node");
+  }
+  const int rc = build_scan(B, ob.first, true, false, true, ref);
+  if (rc != RT_OK) return rc;
+  B->out[at].skip = (int)B->out.size();
   return RT_OK;
 }
 
@@ -794,7 +947,7 @@ DevCamera to_dev_camera(const rt_camera* c) {
 int launch_render(rt_ctx* ctx, const rt_camera* cam, const rt_render_params* p, float* d_sum, float* d_sumsq, bool stats, hipStream_t stream) {
   RenderArgs A;
   A.nx = p->nx; A.ny = p->ny; A.spp = p->spp; A.sample_begin = p->sample_begin; A.max_depth = p->max_depth; A.sky = p->sky;
-  A.t_min = p->t_min; A.shard_index = p->shard_index; A.shard_count = p->shard_count;
+  A.t_min = p->t_min; A.inv_nx = 1.0f / (float)p->nx; A.inv_ny = 1.0f / (float)p->ny; A.shard_index = p->shard_index; A.shard_count = p->shard_count;
   A.key0 = (unsigned)p->seed; A.key1 = (unsigned)(p->seed >> 32);
   A.tiles_x = (p->nx + 7) / 8; A.tiles_y = (p->ny + 7) / 8;
   const size_t n = (size_t)p->nx * p->ny * 3;
@@ -856,13 +1009,21 @@ int rt_upload_scene(rt_ctx* ctx, const rt_scene* s) {
   if (!ctx) return rt::set_error(RT_ERR_INVALID, "rt_upload_scene: null context");
   int rc = validate_scene(s);
   if (rc != RT_OK) return rc;
-  std::vector<ScanNode> scan;
-  rc = build_scan(s, 0, false, 0, &scan);
+  ScanBuilder B;
+  B.s = s;
+  B.leaves.assign((size_t)s->n_nodes, 0);
+  B.prim_obj.assign((size_t)s->n_prims, -1);
+  B.any_interior = false;
+  rc = count_leaves(s, 0, 0, &B.leaves);
+  if (rc < 0) return rc;
+  rc = build_scan(&B, 0, false, false, true, -1);
   if (rc != RT_OK) return rc;
+  const std::vector<ScanNode>& scan = B.out;
   HIP_TRY(hipSetDevice(ctx->device));
   free_scene(ctx);
   if ((rc = upload(&ctx->d_scan, scan.data(), scan.size())) != RT_OK) return rc;
   if ((rc = upload(&ctx->d_prims, s->prims, (size_t)s->n_prims)) != RT_OK) return rc;
+  if ((rc = upload(&ctx->d_prim_obj, B.prim_obj.data(), B.prim_obj.size())) != RT_OK) return rc;
   if ((rc = upload(&ctx->d_objects, s->objects, (size_t)s->n_objects)) != RT_OK) return rc;
   if ((rc = upload(&ctx->d_materials, s->materials, (size_t)s->n_materials)) != RT_OK) return rc;
   if ((rc = upload(&ctx->d_textures, s->textures, (size_t)s->n_textures)) != RT_OK) return rc;
@@ -871,6 +1032,8 @@ int rt_upload_scene(rt_ctx* ctx, const rt_scene* s) {
   std::memset(&d, 0, sizeof(d));
   d.scan = (const ScanNode*)ctx->d_scan;
   d.prims = (const rt_prim*)ctx->d_prims;
+  d.prim_obj = (const int*)ctx->d_prim_obj;
+  d.flat = B.any_interior ? 0 : 1;
   d.objects = (const rt_object*)ctx->d_objects;
   d.materials = (const rt_material*)ctx->d_materials;
   d.textures = (const rt_texture*)ctx->d_textures;

@@ -1,0 +1,18 @@
+#!/bin/bash
+# Profiling recipe for the GPU box (run through gpurun from the repository root).
+# 1) kernel trace + stats of the benchmark command; 2) PMC passes, one counter set per run.
+set -u
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$R/gpurun_out/prof
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-stats > $OUT/trace.log 2>&1 || exit 1
+pass() {
+  name=$1; shift
+  timeout -s KILL 120 rocprofv3 --pmc "$@" --output-format csv -d $OUT/$name -- python3 $R/bench.py --steps 1 --warmup 0 --spp 200 --no-cpu-baseline --no-stats > $OUT/$name.log 2>&1 || exit 1
+}
+pass pmc1 SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY
+pass pmc2 SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_LDS SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_SALU SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_LDS
+pass pmc3 FETCH_SIZE GRBM_GUI_ACTIVE
+pass pmc4 WRITE_SIZE TCC_HIT_sum TCC_MISS_sum
+echo done
