@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "librt_amd.so")
+# RT_AMD_LIB lets a tuning session load another build of the same library.
+LIB_PATH = os.environ.get("RT_AMD_LIB", os.path.join(_HERE, "csrc", "librt_amd.so"))
 
 RT_OK = 0
 RT_ERR_INVALID = -1

@@ -479,7 +479,13 @@ struct RenderArgs {
   int shard_index, shard_count;
   unsigned key0, key1;
   int tiles_x, tiles_y;
+  int n_chunks, chunk_spp;  // the samples of a tile are split into n_chunks work items of chunk_spp samples
 };
+
+// Waves per SIMD the register allocator must leave room for (launch_bounds' second argument).
+#ifndef RT_RENDER_WAVES_PER_SIMD
+#define RT_RENDER_WAVES_PER_SIMD 5
+#endif
 
 #define RT_INV_PI_F 0.31830988618379067154f
 
@@ -487,17 +493,27 @@ struct RenderArgs {
 // render_kernel
 // ---------------------------------------------------------------------------
 template <bool STATS, bool SUMSQ>
-__global__ void __launch_bounds__(256) render_kernel(DevScene S, DevCamera cam, RenderArgs A, float* __restrict__ out_sum,
+__global__ void __launch_bounds__(256, RT_RENDER_WAVES_PER_SIMD) render_kernel(DevScene S, DevCamera cam, RenderArgs A, float* __restrict__ out_sum,
                                                      float* __restrict__ out_sumsq, unsigned long long* __restrict__ stats) {
   __shared__ float acc[4][6][64];
   const int lane = threadIdx.x & 63;
   const int wib = threadIdx.x >> 6;
-  const int tile = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wib);
-  if (tile >= A.tiles_x * A.tiles_y) return;
+  // One wave = one work item = (tile, sample chunk).  With more than one chunk
+  // each item writes its partial sums to its own slab; reduce_slabs_kernel adds
+  // the slabs in a fixed order, so the result does not depend on scheduling.
+  const int item = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wib);
+  const int n_tiles = A.tiles_x * A.tiles_y;
+  if (item >= n_tiles * A.n_chunks) return;
+  const int chunk = item / n_tiles;
+  const int tile = item - chunk * n_tiles;
   const int tx = tile % A.tiles_x, ty = tile / A.tiles_x;
+  const size_t slab = (size_t)chunk * A.nx * A.ny * 3;
+  out_sum += slab;
+  if (SUMSQ) out_sumsq += slab;
+  bool mine = true;
   if (A.shard_count > 1) {
     const int big = ((ty * 8) / 64) * ((A.nx + 63) / 64) + (tx * 8) / 64;
-    if (big % A.shard_count != A.shard_index) return;
+    mine = big % A.shard_count == A.shard_index;
   }
 #pragma unroll
   for (int c = 0; c < (SUMSQ ? 6 : 3); ++c) acc[wib][c][lane] = 0.0f;
@@ -505,7 +521,9 @@ __global__ void __launch_bounds__(256) render_kernel(DevScene S, DevCamera cam, 
   Counters cnt;
   memset(&cnt, 0, sizeof(cnt));
 
-  const int pool_size = 64 * A.spp;
+  const int s_first = chunk * A.chunk_spp;
+  const int s_count = mine ? min(A.chunk_spp, A.spp - s_first) : 0;
+  const int pool_size = 64 * s_count;  // a tile of another shard is written as zeros
   int pool_next = 0;
 
   // Per-lane path state.
@@ -532,7 +550,7 @@ __global__ void __launch_bounds__(256) render_kernel(DevScene S, DevCamera cam, 
         if (px < A.nx && row < A.ny) {
           const int j = A.ny - 1 - row;
           pixel_id = (unsigned)(j * A.nx + px);
-          sample = (unsigned)(A.sample_begin + s);
+          sample = (unsigned)(A.sample_begin + s_first + s);
           U4 w = philox4x32_10(pixel_id, sample, 0u, 0u, A.key0, A.key1);
           const float u = ((float)px + u01(w.x)) * A.inv_nx;
           const float v = ((float)j + u01(w.y)) * A.inv_ny;
@@ -697,6 +715,21 @@ __global__ void __launch_bounds__(256) render_kernel(DevScene S, DevCamera cam, 
 }
 
 // ---------------------------------------------------------------------------
+// reduce_slabs_kernel: out[i] = slab0[i] + slab1[i] + ... in that order.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) reduce_slabs_kernel(const float4* __restrict__ slabs, size_t n4, int n_slabs, float4* __restrict__ out) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    float4 a = slabs[i];
+    for (int c = 1; c < n_slabs; ++c) {
+      const float4 b = slabs[(size_t)c * n4 + i];
+      a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    out[i] = a;
+  }
+}
+
+// ---------------------------------------------------------------------------
 // tonemap_kernel (main.rs:136-155)
 // ---------------------------------------------------------------------------
 __global__ void tonemap_kernel(const float* __restrict__ sum, size_t n, float spp, unsigned char* __restrict__ out) {
@@ -728,6 +761,8 @@ struct rt_ctx {
   void* d_textures;
   void* d_perlins;
   unsigned long long* d_stats;
+  float* d_slabs;       // partial-sum slabs of chunked renders, grown on demand
+  size_t slab_floats;
   hipEvent_t ev0, ev1;
 };
 
@@ -951,19 +986,54 @@ int launch_render(rt_ctx* ctx, const rt_camera* cam, const rt_render_params* p, 
   A.key0 = (unsigned)p->seed; A.key1 = (unsigned)(p->seed >> 32);
   A.tiles_x = (p->nx + 7) / 8; A.tiles_y = (p->ny + 7) / 8;
   const size_t n = (size_t)p->nx * p->ny * 3;
-  if (p->shard_count > 1) {
-    HIP_TRY(hipMemsetAsync(d_sum, 0, n * sizeof(float), stream));
-    if (d_sumsq) HIP_TRY(hipMemsetAsync(d_sumsq, 0, n * sizeof(float), stream));
+  const int n_tiles = A.tiles_x * A.tiles_y;
+  // Load balance: a wave keeps its work item for its whole life, so the grid
+  // needs many times more items than the chip has wave slots (256 CUs x ~24
+  // waves) or the last round leaves most of the chip idle.  Split the samples
+  // of each tile until there are about 30 rounds of items, but keep at least 32
+  // samples per item (the pool's own tail) and the slabs under 1 GiB.
+  const long long want_items = 256LL * 24 * 30;
+  long long chunks = (want_items + n_tiles - 1) / n_tiles;
+  const long long max_by_spp = p->spp / 32 > 1 ? p->spp / 32 : 1;
+  if (chunks > max_by_spp) chunks = max_by_spp;
+  if ((n % 4) != 0) chunks = 1;  // the slab reduction works on float4
+  const size_t per_image = n * (d_sumsq ? 2 : 1);
+  while (chunks > 1 && (size_t)chunks * per_image * sizeof(float) > ((size_t)1 << 30)) --chunks;
+  if (chunks < 1) chunks = 1;
+  A.n_chunks = (int)chunks;
+  A.chunk_spp = (p->spp + A.n_chunks - 1) / A.n_chunks;
+  A.n_chunks = (p->spp + A.chunk_spp - 1) / A.chunk_spp;
+  float* k_sum = d_sum;
+  float* k_sumsq = d_sumsq;
+  if (A.n_chunks > 1) {
+    const size_t need = (size_t)A.n_chunks * per_image;
+    if (need > ctx->slab_floats) {
+      if (ctx->d_slabs) HIP_TRY(hipFree(ctx->d_slabs));
+      ctx->d_slabs = nullptr;
+      ctx->slab_floats = 0;
+      HIP_TRY(hipMalloc((void**)&ctx->d_slabs, need * sizeof(float)));
+      ctx->slab_floats = need;
+    }
+    k_sum = ctx->d_slabs;
+    k_sumsq = d_sumsq ? ctx->d_slabs + (size_t)A.n_chunks * n : nullptr;
   }
   const DevCamera dc = to_dev_camera(cam);
-  const int n_tiles = A.tiles_x * A.tiles_y;
-  const dim3 grid((n_tiles + 3) / 4), block(256);
+  const int n_items = n_tiles * A.n_chunks;
+  const dim3 grid((n_items + 3) / 4), block(256);
   if (stats) {
-    if (d_sumsq) hipLaunchKernelGGL((render_kernel<true, true>), grid, block, 0, stream, ctx->dev, dc, A, d_sum, d_sumsq, ctx->d_stats);
-    else hipLaunchKernelGGL((render_kernel<true, false>), grid, block, 0, stream, ctx->dev, dc, A, d_sum, d_sumsq, ctx->d_stats);
+    if (d_sumsq) hipLaunchKernelGGL((render_kernel<true, true>), grid, block, 0, stream, ctx->dev, dc, A, k_sum, k_sumsq, ctx->d_stats);
+    else hipLaunchKernelGGL((render_kernel<true, false>), grid, block, 0, stream, ctx->dev, dc, A, k_sum, k_sumsq, ctx->d_stats);
   } else {
-    if (d_sumsq) hipLaunchKernelGGL((render_kernel<false, true>), grid, block, 0, stream, ctx->dev, dc, A, d_sum, d_sumsq, ctx->d_stats);
-    else hipLaunchKernelGGL((render_kernel<false, false>), grid, block, 0, stream, ctx->dev, dc, A, d_sum, d_sumsq, ctx->d_stats);
+    if (d_sumsq) hipLaunchKernelGGL((render_kernel<false, true>), grid, block, 0, stream, ctx->dev, dc, A, k_sum, k_sumsq, ctx->d_stats);
+    else hipLaunchKernelGGL((render_kernel<false, false>), grid, block, 0, stream, ctx->dev, dc, A, k_sum, k_sumsq, ctx->d_stats);
+  }
+  HIP_TRY(hipGetLastError());
+  if (A.n_chunks > 1) {
+    const size_t n4 = n / 4;
+    unsigned blocks = (unsigned)((n4 + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(blocks), dim3(256), 0, stream, (const float4*)k_sum, n4, A.n_chunks, (float4*)d_sum);
+    if (d_sumsq) hipLaunchKernelGGL(reduce_slabs_kernel, dim3(blocks), dim3(256), 0, stream, (const float4*)k_sumsq, n4, A.n_chunks, (float4*)d_sumsq);
   }
   HIP_TRY(hipGetLastError());
   return RT_OK;
@@ -999,6 +1069,7 @@ int rt_destroy(rt_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   free_scene(ctx);
   if (ctx->d_stats) (void)hipFree(ctx->d_stats);
+  if (ctx->d_slabs) (void)hipFree(ctx->d_slabs);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
   delete ctx;
