@@ -65,9 +65,28 @@ struct ScanNode {
   int b;  // prim count; for K_OBJ_*: count | xform << 24
 };
 
+// Everything the path loop needs to know about the primitive it hit, gathered
+// with one 64-byte read: geometry, the transform of the object it lives in, and
+// its material with a constant texture already resolved to a colour.
+#define DP_TYPE_MASK 0x3
+#define DP_FLIP 0x4
+#define DP_XFORM_SHIFT 3   // 2 bits: RT_XFORM_*
+#define DP_MAT_SHIFT 5     // 3 bits: RT_MAT_*
+#define DP_TEXTURED 0x100  // the colour must come from Texture::value (checker / noise)
+#define DP_INDEX_SHIFT 12  // material index
+struct DevPrim {
+  int flags;
+  float f[5];
+  float color[3];  // albedo / emission when the texture is constant; Metal albedo
+  float sin_t, cos_t;
+  float off[3];
+  float fuzz, ref_idx;
+};
+
 // Scene buffers are written by rt_upload_scene and only read by kernels, so
-// wave-uniform reads go through the constant address space: that is what makes
-// the compiler emit scalar loads (s_load_dwordx16 into SGPRs) for them.
+// wave-uniform reads go through the constant address space with a vector type:
+// that is what makes the compiler emit one scalar load (s_load_dwordx16 into
+// SGPRs) per record.
 #define RT_CONSTANT_AS __attribute__((address_space(4)))
 typedef unsigned u32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned u32x8 __attribute__((ext_vector_type(8)));
@@ -75,12 +94,11 @@ typedef unsigned u32x8 __attribute__((ext_vector_type(8)));
 struct DevScene {
   const ScanNode* scan;
   const rt_prim* prims;
-  const int* prim_obj;  // object whose frame a primitive lives in, -1 = world frame
-  const rt_object* objects;
+  const DevPrim* dprims;
   const rt_material* materials;
   const rt_texture* textures;
   const rt_perlin* perlins;
-  int n_scan, n_prims, n_objects, n_lights;
+  int n_scan, n_prims, n_lights;
   int flat;  // 1: the scan array holds leaves only (every skip is the next index)
   rt_light light;
 };
@@ -95,6 +113,7 @@ struct F3 {
 };
 __device__ __forceinline__ F3 f3(float x, float y, float z) { F3 r; r.x = x; r.y = y; r.z = z; return r; }
 __device__ __forceinline__ F3 operator*(F3 a, float s) { return f3(a.x * s, a.y * s, a.z * s); }
+__device__ __forceinline__ F3 sel3(bool c, F3 a, F3 b) { return f3(c ? a.x : b.x, c ? a.y : b.y, c ? a.z : b.z); }
 // z*z' + (y*y' + x*x') with single-rounding multiply-adds (the oracle's fused dot).
 __device__ __forceinline__ float dot3(F3 a, F3 b) { return fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x)); }
 
@@ -111,21 +130,22 @@ __device__ __forceinline__ RayF make_ray(F3 o, F3 d) {
 
 // Translate::hit (hitable.rs:440) then RotateY::hit (hitable.rs:510-518): the ray
 // in the object's frame.  d.y, and so inv.y, is unchanged.  WANT_INV = false
-// skips the two reciprocals (the caller only needs o and d).
+// skips the two reciprocals (the caller only needs o and d).  `xform` may differ
+// from lane to lane, so the two steps are selects, not branches.
 template <bool WANT_INV>
 __device__ __forceinline__ RayF to_object_frame(const RayF& w, int xform, float sin_t, float cos_t, float ox, float oy, float oz) {
   RayF r = w;
-  if (xform & RT_XFORM_TRANSLATE) r.o = f3(w.o.x - ox, w.o.y - oy, w.o.z - oz);
-  if (xform & RT_XFORM_ROTATE_Y) {
-    const F3 o = r.o, d = r.d;
-    r.o.x = fmaf(cos_t, o.x, -(sin_t * o.z));
-    r.o.z = fmaf(sin_t, o.x, cos_t * o.z);
-    r.d.x = fmaf(cos_t, d.x, -(sin_t * d.z));
-    r.d.z = fmaf(sin_t, d.x, cos_t * d.z);
-    if (WANT_INV) {
-      r.inv.x = 1.0f / r.d.x;
-      r.inv.z = 1.0f / r.d.z;
-    }
+  const bool tr = (xform & RT_XFORM_TRANSLATE) != 0, ro = (xform & RT_XFORM_ROTATE_Y) != 0;
+  r.o = sel3(tr, f3(w.o.x - ox, w.o.y - oy, w.o.z - oz), w.o);
+  const F3 o = r.o, d = r.d;
+  r.o.x = ro ? fmaf(cos_t, o.x, -(sin_t * o.z)) : o.x;
+  r.o.z = ro ? fmaf(sin_t, o.x, cos_t * o.z) : o.z;
+  r.d.x = ro ? fmaf(cos_t, d.x, -(sin_t * d.z)) : d.x;
+  r.d.z = ro ? fmaf(sin_t, d.x, cos_t * d.z) : d.z;
+  if (WANT_INV) {
+    // d is unchanged without a rotation, so 1/d is the same value either way.
+    r.inv.x = 1.0f / r.d.x;
+    r.inv.z = 1.0f / r.d.z;
   }
   return r;
 }
@@ -151,6 +171,13 @@ struct Hit {
   float t;
   int prim;  // index into prims, -1 = none
 };
+
+// The control flow below is wave-uniform wherever possible: per-lane conditions
+// become selects ("h & on"), not branches, because a wave of incoherent rays
+// executes both sides anyway and exec-mask bookkeeping only adds scalar work.
+// Lanes that take no part (dead paths, rays past the end of a batch) run the same
+// arithmetic on stale registers; they never touch memory and their results are
+// masked out.
 
 // Aabb::hit (bvh.rs:46-61) with the reference's comparisons: a NaN slab value
 // leaves the interval unchanged (v_max/v_min return the other operand), a
@@ -202,27 +229,22 @@ __device__ __forceinline__ bool rect_test(const float* f, const RayF& r, float t
 }
 
 // Sphere::hit (hitable.rs:50-82): half-b quadratic, nearer root first, strict
-// bounds; f = cx,cy,cz,r.
+// bounds; f = cx,cy,cz,r.  A negative discriminant makes the square root, and with
+// it every comparison, fail on its own; disc == 0 is excluded as in the source.
 __device__ __forceinline__ bool sphere_test(const float* f, const RayF& r, float t_min, float t_max, float& t_out) {
   const F3 oc = f3(r.o.x - f[0], r.o.y - f[1], r.o.z - f[2]);
   const float a = dot3(r.d, r.d);
   const float b = dot3(oc, r.d);
   const float c = fmaf(-f[3], f[3], dot3(oc, oc));
   const float disc = fmaf(b, b, -(a * c));
-  bool hit = false;
-  if (disc > 0.0f) {
-    const float sq = sqrtf(disc);
-    const float inv_a = 1.0f / a;
-    float temp = (-b - sq) * inv_a;
-    if (temp < t_max && temp > t_min) {
-      hit = true;
-    } else {
-      temp = (-b + sq) * inv_a;
-      hit = temp < t_max && temp > t_min;
-    }
-    t_out = temp;
-  }
-  return hit;
+  const float sq = sqrtf(disc);
+  const float inv_a = 1.0f / a;
+  const float t_near = (-b - sq) * inv_a;
+  const float t_far = (-b + sq) * inv_a;
+  const bool near_ok = (t_near < t_max) & (t_near > t_min);
+  const bool far_ok = (t_far < t_max) & (t_far > t_min);
+  t_out = near_ok ? t_near : t_far;
+  return (disc > 0.0f) & (near_ok | far_ok);
 }
 
 // HitableList::hit (hitable.rs:105-117) over prims[first, first+count) with a
@@ -236,29 +258,26 @@ __device__ __forceinline__ void list_test(const rt_prim* __restrict__ prims, int
   float loc_t = t_max;
   int loc_prim = -1;
   for (int qi = first; qi < first + count; ++qi) {
-    const rt_prim q = load_prim_uniform(prims, __builtin_amdgcn_readfirstlane(qi));
+    const int qu = __builtin_amdgcn_readfirstlane(qi);
+    const rt_prim q = load_prim_uniform(prims, qu);
     const int type = q.type & RT_PRIM_TYPE_MASK;
     float t = 0.0f;
-    bool h = false;
-    if (lane_on) {
-      if (type == RT_PRIM_XY_RECT) h = rect_test<2, 0, 1>(q.f, r, t_min, loc_t, t);
-      else if (type == RT_PRIM_XZ_RECT) h = rect_test<1, 0, 2>(q.f, r, t_min, loc_t, t);
-      else if (type == RT_PRIM_YZ_RECT) h = rect_test<0, 1, 2>(q.f, r, t_min, loc_t, t);
-      else h = sphere_test(q.f, r, t_min, loc_t, t);
-      if (STATS) {
-        if (type == RT_PRIM_SPHERE) cnt.sphere_tests++;
-        else cnt.rect_tests++;
-      }
+    bool h;
+    if (type == RT_PRIM_XY_RECT) h = rect_test<2, 0, 1>(q.f, r, t_min, loc_t, t);
+    else if (type == RT_PRIM_XZ_RECT) h = rect_test<1, 0, 2>(q.f, r, t_min, loc_t, t);
+    else if (type == RT_PRIM_YZ_RECT) h = rect_test<0, 1, 2>(q.f, r, t_min, loc_t, t);
+    else h = sphere_test(q.f, r, t_min, loc_t, t);
+    h &= lane_on;
+    if (STATS) {
+      if (type == RT_PRIM_SPHERE) cnt.sphere_tests += lane_on;
+      else cnt.rect_tests += lane_on;
     }
-    if (h) {
-      loc_t = t;
-      loc_prim = qi;
-    }
+    loc_t = h ? t : loc_t;
+    loc_prim = h ? qu : loc_prim;
   }
-  if (loc_prim >= 0 && !(best.t < loc_t)) {
-    best.t = loc_t;
-    best.prim = loc_prim;
-  }
+  const bool take = (loc_prim >= 0) & !(best.t < loc_t);
+  best.t = take ? loc_t : best.t;
+  best.prim = take ? loc_prim : best.prim;
 }
 
 __device__ __forceinline__ int wave_min_i32(int v) {
@@ -288,48 +307,35 @@ __device__ __forceinline__ void scan_range(const DevScene& S, int begin, int end
     // readfirstlane pins the index to an SGPR so the node arrives by scalar load.
     i = __builtin_amdgcn_readfirstlane(i);
     const ScanNode n = load_node(S.scan, i);
-    bool on = false;
-    if (act) {
-      on = slab_test(n, r, sg, t_min, t_max, best.t);
-      if (STATS) cnt.node_tests++;
-      if (!FLAT && !on) lane_next = n.skip;
-    }
+    const bool on = act & slab_test(n, r, sg, t_min, t_max, best.t);
+    if (STATS) cnt.node_tests += act;
+    if (!FLAT) lane_next = (act & !on) ? n.skip : lane_next;
     const int kind = n.kind;
     if (kind >= K_RECT_XY && kind <= K_RECT_YZ) {
       // A single rect: its own t_max test against the running best is the tie rule.
-      float t = 0.0f;
-      bool h = false;
-      if (on) {
-        if (kind == K_RECT_XY) h = rect_test<2, 0, 1>(n.f, r, t_min, best.t, t);
-        else if (kind == K_RECT_XZ) h = rect_test<1, 0, 2>(n.f, r, t_min, best.t, t);
-        else h = rect_test<0, 1, 2>(n.f, r, t_min, best.t, t);
-        if (STATS) cnt.rect_tests++;
-      }
-      if (h) {
-        best.t = t;
-        best.prim = n.a;
-      }
+      float t;
+      bool h;
+      if (kind == K_RECT_XY) h = rect_test<2, 0, 1>(n.f, r, t_min, best.t, t);
+      else if (kind == K_RECT_XZ) h = rect_test<1, 0, 2>(n.f, r, t_min, best.t, t);
+      else h = rect_test<0, 1, 2>(n.f, r, t_min, best.t, t);
+      h &= on;
+      if (STATS) cnt.rect_tests += on;
+      best.t = h ? t : best.t;
+      best.prim = h ? n.a : best.prim;
     } else if (kind == K_SPHERE) {
-      float t = 0.0f;
-      bool h = false;
-      if (on) {
-        h = sphere_test(n.f, r, t_min, t_max, t);
-        if (STATS) cnt.sphere_tests++;
-      }
-      if (h && !(best.t < t)) {
-        best.t = t;
-        best.prim = n.a;
-      }
+      float t;
+      bool h = sphere_test(n.f, r, t_min, t_max, t) & on;
+      if (STATS) cnt.sphere_tests += on;
+      h &= !(best.t < t);
+      best.t = h ? t : best.t;
+      best.prim = h ? n.a : best.prim;
     } else if (kind == K_LIST) {
       if (__ballot(on) != 0ull) list_test<STATS>(S.prims, n.a, n.b, on, r, t_min, t_max, best, cnt);
     } else if (kind == K_OBJ_LIST || kind == K_OBJ_BVH) {
       if (LEVEL == 0) {
         if (__ballot(on) != 0ull) {
-          RayF q = r;
-          if (on) {
-            q = to_object_frame<true>(r, n.b >> 24, n.f[0], n.f[1], n.f[2], n.f[3], n.f[4]);
-            if (STATS) cnt.instance_ops++;
-          }
+          const RayF q = to_object_frame<true>(r, n.b >> 24, n.f[0], n.f[1], n.f[2], n.f[3], n.f[4]);
+          if (STATS) cnt.instance_ops += on;
           if (kind == K_OBJ_LIST) list_test<STATS>(S.prims, n.a, n.b & 0xffffff, on, q, t_min, t_max, best, cnt);
           else scan_range<STATS, false, 1>(S, i + 1, n.skip, on, q, t_min, t_max, best, cnt);
         }
@@ -356,46 +362,30 @@ __device__ __forceinline__ Hit trace_scan(const DevScene& S, bool active, const 
 
 struct Surface {
   F3 p, normal;
-  int material;
 };
 
 // The HitRecord fields color() needs (hitable.rs:175-182, 62-67), carried back
 // to the world frame by RotateY::hit (hitable.rs:521-528) and Translate::hit
-// (hitable.rs:442).
-__device__ __forceinline__ Surface finalize_hit(const DevScene& S, const RayF& w, const Hit& h) {
+// (hitable.rs:442).  `q` is the hit primitive's DevPrim.
+__device__ __forceinline__ Surface finalize_hit(const DevPrim& q, const RayF& w, float t) {
   Surface s;
-  const rt_prim q = S.prims[h.prim];
-  const int obj = S.prim_obj[h.prim];
-  RayF r = w;
-  int xform = 0;
-  float sin_t = 0.0f, cos_t = 1.0f, ox = 0.0f, oy = 0.0f, oz = 0.0f;
-  if (obj >= 0) {
-    const rt_object ob = S.objects[obj];
-    xform = ob.xform; sin_t = ob.sin_theta; cos_t = ob.cos_theta;
-    ox = ob.offset[0]; oy = ob.offset[1]; oz = ob.offset[2];
-    r = to_object_frame<false>(w, xform, sin_t, cos_t, ox, oy, oz);
-  }
-  F3 p = f3(fmaf(h.t, r.d.x, r.o.x), fmaf(h.t, r.d.y, r.o.y), fmaf(h.t, r.d.z, r.o.z));
-  F3 nrm;
-  const int type = q.type & RT_PRIM_TYPE_MASK;
-  if (type == RT_PRIM_SPHERE) {
-    const float inv_r = 1.0f / q.f[3];
-    nrm = f3((p.x - q.f[0]) * inv_r, (p.y - q.f[1]) * inv_r, (p.z - q.f[2]) * inv_r);
-  } else {
-    const float sgn = (q.type & RT_PRIM_FLIP) ? -1.0f : 1.0f;
-    nrm = f3(type == RT_PRIM_YZ_RECT ? sgn : 0.0f, type == RT_PRIM_XZ_RECT ? sgn : 0.0f, type == RT_PRIM_XY_RECT ? sgn : 0.0f);
-  }
-  if (xform & RT_XFORM_ROTATE_Y) {
-    const F3 pl = p, nl = nrm;
-    p.x = fmaf(cos_t, pl.x, sin_t * pl.z);
-    p.z = fmaf(-sin_t, pl.x, cos_t * pl.z);
-    nrm.x = fmaf(cos_t, nl.x, sin_t * nl.z);
-    nrm.z = fmaf(-sin_t, nl.x, cos_t * nl.z);
-  }
-  if (xform & RT_XFORM_TRANSLATE) p = f3(p.x + ox, p.y + oy, p.z + oz);
+  const int xform = (q.flags >> DP_XFORM_SHIFT) & 3;
+  const RayF r = to_object_frame<false>(w, xform, q.sin_t, q.cos_t, q.off[0], q.off[1], q.off[2]);
+  F3 p = f3(fmaf(t, r.d.x, r.o.x), fmaf(t, r.d.y, r.o.y), fmaf(t, r.d.z, r.o.z));
+  const int type = q.flags & DP_TYPE_MASK;
+  const float inv_r = 1.0f / q.f[3];
+  const float sgn = (q.flags & DP_FLIP) ? -1.0f : 1.0f;
+  F3 nrm = f3(type == RT_PRIM_YZ_RECT ? sgn : 0.0f, type == RT_PRIM_XZ_RECT ? sgn : 0.0f, type == RT_PRIM_XY_RECT ? sgn : 0.0f);
+  nrm = sel3(type == RT_PRIM_SPHERE, f3((p.x - q.f[0]) * inv_r, (p.y - q.f[1]) * inv_r, (p.z - q.f[2]) * inv_r), nrm);
+  const bool ro = (xform & RT_XFORM_ROTATE_Y) != 0, tr = (xform & RT_XFORM_TRANSLATE) != 0;
+  const F3 pl = p, nl = nrm;
+  p.x = ro ? fmaf(q.cos_t, pl.x, q.sin_t * pl.z) : pl.x;
+  p.z = ro ? fmaf(-q.sin_t, pl.x, q.cos_t * pl.z) : pl.z;
+  nrm.x = ro ? fmaf(q.cos_t, nl.x, q.sin_t * nl.z) : nl.x;
+  nrm.z = ro ? fmaf(-q.sin_t, nl.x, q.cos_t * nl.z) : nl.z;
+  p = sel3(tr, f3(p.x + q.off[0], p.y + q.off[1], p.z + q.off[2]), p);
   s.p = p;
   s.normal = nrm;
-  s.material = q.material;
   return s;
 }
 
@@ -421,7 +411,7 @@ __global__ void __launch_bounds__(256) trace_kernel(DevScene S, const float* __r
         Surface s;
         s.p = f3(0, 0, 0);
         s.normal = f3(0, 0, 0);
-        if (h.prim >= 0) s = finalize_hit(S, w, h);
+        if (h.prim >= 0) s = finalize_hit(S.dprims[h.prim], w, h.t);
         if (normal) { normal[3 * idx] = s.normal.x; normal[3 * idx + 1] = s.normal.y; normal[3 * idx + 2] = s.normal.z; }
         if (p_out) { p_out[3 * idx] = s.p.x; p_out[3 * idx + 1] = s.p.y; p_out[3 * idx + 2] = s.p.z; }
       }
@@ -467,12 +457,6 @@ __device__ __forceinline__ F3 cross3(F3 a, F3 b) {  // vec3.rs:180-186
 }
 __device__ __forceinline__ F3 unit3(F3 a) { return a * fast_rsq(dot3(a, a)); }  // vec3.rs:188-190
 
-// Texture::value (texture.rs:22-35).  This build evaluates constant textures.
-__device__ __forceinline__ F3 texture_value(const DevScene& S, int tex, F3 p) {
-  const rt_texture t = S.textures[tex];
-  return f3(t.color[0], t.color[1], t.color[2]);
-}
-
 struct RenderArgs {
   int nx, ny, spp, sample_begin, max_depth, sky;
   float t_min, inv_nx, inv_ny;
@@ -484,7 +468,7 @@ struct RenderArgs {
 
 // Waves per SIMD the register allocator must leave room for (launch_bounds' second argument).
 #ifndef RT_RENDER_WAVES_PER_SIMD
-#define RT_RENDER_WAVES_PER_SIMD 5
+#define RT_RENDER_WAVES_PER_SIMD 6
 #endif
 
 #define RT_INV_PI_F 0.31830988618379067154f
@@ -537,46 +521,57 @@ __global__ void __launch_bounds__(256, RT_RENDER_WAVES_PER_SIMD) render_kernel(D
 
   for (;;) {
     // ---- refill dead lanes from the pool (main.rs:101-107) ----
+    // Every lane builds a camera ray for the item it would take; only lanes that
+    // are dead and got an item keep it.
     const unsigned long long need = __ballot(!alive);
     if (need != 0ull && pool_next < pool_size) {
       const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(need >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)need, 0));
       const int k = pool_next + rank;
       pool_next += __popcll(need);
-      if (!alive && k < pool_size) {
-        pix = k & 63;
-        const int s = k >> 6;
-        const int px = tx * 8 + (pix & 7);
-        const int row = ty * 8 + (pix >> 3);  // output row, top first
-        if (px < A.nx && row < A.ny) {
-          const int j = A.ny - 1 - row;
-          pixel_id = (unsigned)(j * A.nx + px);
-          sample = (unsigned)(A.sample_begin + s_first + s);
-          U4 w = philox4x32_10(pixel_id, sample, 0u, 0u, A.key0, A.key1);
-          const float u = ((float)px + u01(w.x)) * A.inv_nx;
-          const float v = ((float)j + u01(w.y)) * A.inv_ny;
-          // camera.rs:53-75
-          float rdx = 0.0f, rdy = 0.0f;
-          if (cam.lens_radius != 0.0f) {
-            unsigned attempt = 0;
-            for (;;) {
-              const float dx = 2.0f * u01(w.z) - 1.0f, dy = 2.0f * u01(w.w) - 1.0f;
-              if (fmaf(dy, dy, dx * dx) < 1.0f) { rdx = cam.lens_radius * dx; rdy = cam.lens_radius * dy; break; }
-              ++attempt;
-              w = philox4x32_10(pixel_id, sample, 0u, attempt, A.key0, A.key1);
-            }
-          }
-          const F3 offset = f3(fmaf(cam.v[0], rdy, cam.u[0] * rdx), fmaf(cam.v[1], rdy, cam.u[1] * rdx), fmaf(cam.v[2], rdy, cam.u[2] * rdx));
-          const F3 org = f3(cam.origin[0] + offset.x, cam.origin[1] + offset.y, cam.origin[2] + offset.z);
-          const F3 dir = f3(fmaf(v, cam.vertical[0], fmaf(u, cam.horizontal[0], cam.llc[0])) - cam.origin[0] - offset.x,
-                            fmaf(v, cam.vertical[1], fmaf(u, cam.horizontal[1], cam.llc[1])) - cam.origin[1] - offset.y,
-                            fmaf(v, cam.vertical[2], fmaf(u, cam.horizontal[2], cam.llc[2])) - cam.origin[2] - offset.z);
-          ray = make_ray(org, dir);
-          thr = f3(1.0f, 1.0f, 1.0f);
-          depth = 0;
-          alive = true;
-          if (STATS) cnt.paths++;
+      const bool take = !alive & (k < pool_size);
+      const int kk = take ? k : 0;
+      const int c_pix = kk & 63;
+      const int s = kk >> 6;
+      const int px = tx * 8 + (c_pix & 7);
+      const int row = ty * 8 + (c_pix >> 3);  // output row, top first
+      const int j = A.ny - 1 - row;
+      const unsigned c_pixel_id = (unsigned)(j * A.nx + px);
+      const unsigned c_sample = (unsigned)(A.sample_begin + s_first + s);
+      U4 w = philox4x32_10(c_pixel_id, c_sample, 0u, 0u, A.key0, A.key1);
+      const float u = ((float)px + u01(w.x)) * A.inv_nx;
+      const float v = ((float)j + u01(w.y)) * A.inv_ny;
+      // camera.rs:53-75
+      float rdx = 0.0f, rdy = 0.0f;
+      if (cam.lens_radius != 0.0f) {
+        unsigned attempt = 0;
+        bool looking = true;
+        while (__ballot(looking) != 0ull) {
+          const float dx = 2.0f * u01(w.z) - 1.0f, dy = 2.0f * u01(w.w) - 1.0f;
+          const bool ok = looking & (fmaf(dy, dy, dx * dx) < 1.0f);
+          rdx = ok ? cam.lens_radius * dx : rdx;
+          rdy = ok ? cam.lens_radius * dy : rdy;
+          looking &= !ok;
+          ++attempt;
+          w = philox4x32_10(c_pixel_id, c_sample, 0u, attempt, A.key0, A.key1);
         }
       }
+      const F3 offset = f3(fmaf(cam.v[0], rdy, cam.u[0] * rdx), fmaf(cam.v[1], rdy, cam.u[1] * rdx), fmaf(cam.v[2], rdy, cam.u[2] * rdx));
+      const F3 org = f3(cam.origin[0] + offset.x, cam.origin[1] + offset.y, cam.origin[2] + offset.z);
+      const F3 dir = f3(fmaf(v, cam.vertical[0], fmaf(u, cam.horizontal[0], cam.llc[0])) - cam.origin[0] - offset.x,
+                        fmaf(v, cam.vertical[1], fmaf(u, cam.horizontal[1], cam.llc[1])) - cam.origin[1] - offset.y,
+                        fmaf(v, cam.vertical[2], fmaf(u, cam.horizontal[2], cam.llc[2])) - cam.origin[2] - offset.z);
+      const RayF fresh = make_ray(org, dir);
+      const bool start = take & (px < A.nx) & (row < A.ny);
+      ray.o = sel3(start, fresh.o, ray.o);
+      ray.d = sel3(start, fresh.d, ray.d);
+      ray.inv = sel3(start, fresh.inv, ray.inv);
+      thr = sel3(start, f3(1.0f, 1.0f, 1.0f), thr);
+      depth = start ? 0 : depth;
+      pix = start ? c_pix : pix;
+      pixel_id = start ? c_pixel_id : pixel_id;
+      sample = start ? c_sample : sample;
+      alive |= start;
+      if (STATS) cnt.paths += start;
     }
     if (__ballot(alive) == 0ull) {
       if (pool_next >= pool_size) break;
@@ -584,107 +579,100 @@ __global__ void __launch_bounds__(256, RT_RENDER_WAVES_PER_SIMD) render_kernel(D
     }
 
     // ---- world.hit(r, 0.001, INFINITY), main.rs:166 ----
-    if (STATS && alive) cnt.rays++;
+    if (STATS) cnt.rays += alive;
     const Hit h = trace_scan<STATS>(S, alive, ray, A.t_min, INFINITY, cnt);
 
-    if (alive) {
-      F3 radiance = f3(0, 0, 0);  // what this vertex adds to the sample, before de_nan
-      bool done = true;
-      if (h.prim < 0) {
-        // main.rs:203-208
-        if (A.sky == RT_SKY_GRADIENT) {
-          const F3 ud = unit3(ray.d);
-          const float t = 0.5f * (ud.y + 1.0f);
-          radiance = f3(thr.x * ((1.0f - t) + t * 0.5f), thr.y * ((1.0f - t) + t * 0.7f), thr.z * ((1.0f - t) + t * 1.0f));
+    // ---- color(), main.rs:165-209, one vertex; every lane runs it, dead lanes and
+    // misses on primitive 0 with their results masked ----
+    const bool hit = alive & (h.prim >= 0);
+    const DevPrim q = S.dprims[hit ? h.prim : 0];
+    const Surface sf = finalize_hit(q, ray, h.t);
+    const int mat_type = (q.flags >> DP_MAT_SHIFT) & 7;
+    const F3 color = f3(q.color[0], q.color[1], q.color[2]);
+    if (STATS) cnt.hits += hit;
+
+    // material.rs:197-203: a light emits towards the side its normal points to and never scatters.
+    const bool is_light = mat_type == RT_MAT_DIFFUSE_LIGHT;
+    const bool emits = hit & is_light & (dot3(sf.normal, ray.d) < 0.0f);
+    // main.rs:203-208
+    F3 sky = f3(0, 0, 0);
+    if (A.sky == RT_SKY_GRADIENT) {
+      const F3 ud = unit3(ray.d);
+      const float t = 0.5f * (ud.y + 1.0f);
+      sky = f3((1.0f - t) + t * 0.5f, (1.0f - t) + t * 0.7f, (1.0f - t) + t * 1.0f);
+    }
+    const F3 le = sel3(emits, color, sel3(hit, f3(0, 0, 0), sky));
+    const F3 radiance = f3(thr.x * le.x, thr.y * le.y, thr.z * le.z);  // what this vertex adds to the sample, before de_nan
+
+    // Lambertian under MixturePDF(HitablePDF(light), CosinePDF(normal)), main.rs:173-197.
+    const bool scatters = hit & !is_light & (depth < A.max_depth);
+    if (STATS) cnt.shade_events += scatters;
+    const U4 w = philox4x32_10(pixel_id, sample, 1u + (unsigned)depth, 0u, A.key0, A.key1);
+    const float xi1 = u01(w.y), xi2 = u01(w.z);
+    // onb.rs:10-21
+    const F3 ww = unit3(sf.normal);
+    const F3 a = fabsf(ww.x) > 0.9f ? f3(0, 1, 0) : f3(1, 0, 0);
+    const F3 vv = unit3(cross3(ww, a));
+    const F3 uu = cross3(ww, vv);
+    const bool pick_light = (S.n_lights > 0) & ((w.x >> 31) != 0u);
+    // XZRect::random, hitable.rs:256-264
+    const F3 dir_light = f3(fmaf(xi1, S.light.f[1] - S.light.f[0], S.light.f[0]) - sf.p.x, S.light.f[4] - sf.p.y,
+                            fmaf(xi2, S.light.f[3] - S.light.f[2], S.light.f[2]) - sf.p.z);
+    // random_cosine_direction, main.rs:239-249 (x and y keep the source's factor 2);
+    // v_sin/v_cos take their argument in turns, so phi = 2*pi*r1 is r1 turns.
+    const float cz = fast_sqrt(1.0f - xi2);
+    const float r2s = 2.0f * fast_sqrt(xi2);
+    const float cx = __builtin_amdgcn_cosf(xi1) * r2s;
+    const float cy = __builtin_amdgcn_sinf(xi1) * r2s;
+    const F3 dir_cos = f3(fmaf(cz, ww.x, fmaf(cy, vv.x, cx * uu.x)), fmaf(cz, ww.y, fmaf(cy, vv.y, cx * uu.y)), fmaf(cz, ww.z, fmaf(cy, vv.z, cx * uu.z)));
+    const F3 dir = sel3(pick_light, dir_light, dir_cos);
+    const float dlen2 = dot3(dir, dir);
+    const float inv_len = fast_rsq(dlen2);
+    // pdf.rs:19-26
+    const float cos_w = dot3(dir, ww) * inv_len;
+    float pdf_val = cos_w > 0.0f ? cos_w * RT_INV_PI_F : 0.0f;
+    if (S.n_lights > 0) {
+      // XZRect::pdf_value, hitable.rs:245-254 (its hit test uses 0.001 and f64::MAX)
+      if (STATS) cnt.light_tests += scatters;
+      const float t = (S.light.f[4] - sf.p.y) * fast_rcp(dir.y);
+      const float lx = fmaf(t, dir.x, sf.p.x), lz = fmaf(t, dir.z, sf.p.z);
+      const bool miss = (t < 0.001f) | (t > 3.402823466e+38f) | (lx < S.light.f[0]) | (lx > S.light.f[1]) | (lz < S.light.f[2]) | (lz > S.light.f[3]);
+      const float area = (S.light.f[1] - S.light.f[0]) * (S.light.f[3] - S.light.f[2]);
+      const float cosine = fabsf(dir.y * inv_len);
+      const float lp = miss ? 0.0f : (t * t * dlen2) * fast_rcp(cosine * area);
+      pdf_val = 0.5f * lp + 0.5f * pdf_val;
+    }
+    // material.rs:76-82
+    const float cos_n = fmaxf(dot3(sf.normal, dir) * inv_len, 0.0f);
+    const float f = (cos_n * RT_INV_PI_F) * fast_rcp(pdf_val);
+    const F3 thr_next = f3(thr.x * color.x * f, thr.y * color.y * f, thr.z * color.z * f);
+    // A zero or NaN weight fixes the sample's value (0 after de_nan) whatever the
+    // rest of the path does, so the path ends there.
+    const bool go_on = scatters & ((thr_next.x > 0.0f) | (thr_next.y > 0.0f) | (thr_next.z > 0.0f));
+    const bool done = alive & !go_on;
+    if (done) {
+      // de_nan (main.rs:252-264) then col += (main.rs:108)
+      const float r = radiance.x != radiance.x ? 0.0f : radiance.x;
+      const float g = radiance.y != radiance.y ? 0.0f : radiance.y;
+      const float b = radiance.z != radiance.z ? 0.0f : radiance.z;
+      if (r != 0.0f || g != 0.0f || b != 0.0f) {
+        atomicAdd(&acc[wib][0][pix], r);
+        atomicAdd(&acc[wib][1][pix], g);
+        atomicAdd(&acc[wib][2][pix], b);
+        if (SUMSQ) {
+          atomicAdd(&acc[wib][3][pix], r * r);
+          atomicAdd(&acc[wib][4][pix], g * g);
+          atomicAdd(&acc[wib][5][pix], b * b);
         }
-      } else {
-        if (STATS) cnt.hits++;
-        const Surface sf = finalize_hit(S, ray, h);
-        const rt_material m = S.materials[sf.material];
-        if (m.type == RT_MAT_DIFFUSE_LIGHT) {
-          // material.rs:197-203: emits towards the side its normal points to; never scatters.
-          if (dot3(sf.normal, ray.d) < 0.0f) {
-            const F3 e = texture_value(S, m.texture, sf.p);
-            radiance = f3(thr.x * e.x, thr.y * e.y, thr.z * e.z);
-          }
-        } else if (depth < A.max_depth) {
-          // Lambertian under MixturePDF(HitablePDF(light), CosinePDF(normal)), main.rs:173-197.
-          if (STATS) cnt.shade_events++;
-          const F3 albedo = texture_value(S, m.texture, sf.p);
-          const U4 w = philox4x32_10(pixel_id, sample, 1u + (unsigned)depth, 0u, A.key0, A.key1);
-          const float xi1 = u01(w.y), xi2 = u01(w.z);
-          // onb.rs:10-21
-          const F3 ww = unit3(sf.normal);
-          const F3 a = fabsf(ww.x) > 0.9f ? f3(0, 1, 0) : f3(1, 0, 0);
-          const F3 vv = unit3(cross3(ww, a));
-          const F3 uu = cross3(ww, vv);
-          F3 dir;
-          const bool pick_light = (S.n_lights > 0) && (w.x >> 31);
-          if (pick_light) {
-            // XZRect::random, hitable.rs:256-264
-            dir = f3(fmaf(xi1, S.light.f[1] - S.light.f[0], S.light.f[0]) - sf.p.x, S.light.f[4] - sf.p.y,
-                     fmaf(xi2, S.light.f[3] - S.light.f[2], S.light.f[2]) - sf.p.z);
-          } else {
-            // random_cosine_direction, main.rs:239-249 (x and y keep the source's factor 2);
-            // v_sin/v_cos take their argument in turns, so phi = 2*pi*r1 is r1 turns.
-            const float z = fast_sqrt(1.0f - xi2);
-            const float r2s = 2.0f * fast_sqrt(xi2);
-            const float x = __builtin_amdgcn_cosf(xi1) * r2s;
-            const float y = __builtin_amdgcn_sinf(xi1) * r2s;
-            dir = f3(fmaf(z, ww.x, fmaf(y, vv.x, x * uu.x)), fmaf(z, ww.y, fmaf(y, vv.y, x * uu.y)), fmaf(z, ww.z, fmaf(y, vv.z, x * uu.z)));
-          }
-          const float dlen2 = dot3(dir, dir);
-          const float inv_len = fast_rsq(dlen2);
-          // pdf.rs:19-26
-          const float cos_w = dot3(dir, ww) * inv_len;
-          float pdf_val = cos_w > 0.0f ? cos_w * RT_INV_PI_F : 0.0f;
-          if (S.n_lights > 0) {
-            // XZRect::pdf_value, hitable.rs:245-254 (its hit test uses 0.001 and f64::MAX)
-            if (STATS) cnt.light_tests++;
-            float lp = 0.0f;
-            const float t = (S.light.f[4] - sf.p.y) * fast_rcp(dir.y);
-            const float lx = fmaf(t, dir.x, sf.p.x), lz = fmaf(t, dir.z, sf.p.z);
-            const bool miss = (t < 0.001f) | (t > 3.402823466e+38f) | (lx < S.light.f[0]) | (lx > S.light.f[1]) | (lz < S.light.f[2]) | (lz > S.light.f[3]);
-            if (!miss) {
-              const float area = (S.light.f[1] - S.light.f[0]) * (S.light.f[3] - S.light.f[2]);
-              const float cosine = fabsf(dir.y * inv_len);
-              lp = (t * t * dlen2) * fast_rcp(cosine * area);
-            }
-            pdf_val = 0.5f * lp + 0.5f * pdf_val;
-          }
-          // material.rs:76-82
-          float cos_n = dot3(sf.normal, dir) * inv_len;
-          if (cos_n < 0.0f) cos_n = 0.0f;
-          const float f = (cos_n * RT_INV_PI_F) * fast_rcp(pdf_val);
-          thr = f3(thr.x * albedo.x * f, thr.y * albedo.y * f, thr.z * albedo.z * f);
-          // A zero or NaN weight fixes the sample's value (0 after de_nan) whatever
-          // the rest of the path does, so the path ends here.
-          const bool dead_weight = !(thr.x > 0.0f || thr.y > 0.0f || thr.z > 0.0f);
-          if (!dead_weight) {
-            ray = make_ray(sf.p, dir);
-            depth += 1;
-            done = false;
-          }
-        }
-      }
-      if (done) {
-        // de_nan (main.rs:252-264) then col += (main.rs:108)
-        const float r = radiance.x != radiance.x ? 0.0f : radiance.x;
-        const float g = radiance.y != radiance.y ? 0.0f : radiance.y;
-        const float b = radiance.z != radiance.z ? 0.0f : radiance.z;
-        if (r != 0.0f || g != 0.0f || b != 0.0f) {
-          atomicAdd(&acc[wib][0][pix], r);
-          atomicAdd(&acc[wib][1][pix], g);
-          atomicAdd(&acc[wib][2][pix], b);
-          if (SUMSQ) {
-            atomicAdd(&acc[wib][3][pix], r * r);
-            atomicAdd(&acc[wib][4][pix], g * g);
-            atomicAdd(&acc[wib][5][pix], b * b);
-          }
-        }
-        alive = false;
       }
     }
+    const RayF next = make_ray(sf.p, dir);
+    ray.o = sel3(go_on, next.o, ray.o);
+    ray.d = sel3(go_on, next.d, ray.d);
+    ray.inv = sel3(go_on, next.inv, ray.inv);
+    thr = sel3(go_on, thr_next, thr);
+    depth += go_on ? 1 : 0;
+    alive = go_on;
   }
 
   // ---- write the tile (main.rs:112-114; sums, not means) ----
@@ -755,8 +743,7 @@ struct rt_ctx {
   DevScene dev;
   void* d_scan;
   void* d_prims;
-  void* d_prim_obj;
-  void* d_objects;
+  void* d_dprims;
   void* d_materials;
   void* d_textures;
   void* d_perlins;
@@ -779,7 +766,7 @@ int hip_fail(hipError_t e, const char* what) {
   } while (0)
 
 void free_scene(rt_ctx* ctx) {
-  void** ptrs[] = {&ctx->d_scan, &ctx->d_prims, &ctx->d_prim_obj, &ctx->d_objects, &ctx->d_materials, &ctx->d_textures, &ctx->d_perlins};
+  void** ptrs[] = {&ctx->d_scan, &ctx->d_prims, &ctx->d_dprims, &ctx->d_materials, &ctx->d_textures, &ctx->d_perlins};
   for (size_t i = 0; i < sizeof(ptrs) / sizeof(ptrs[0]); ++i) {
     if (*ptrs[i]) (void)hipFree(*ptrs[i]);
     *ptrs[i] = nullptr;
@@ -795,6 +782,7 @@ int validate_scene(const rt_scene* s) {
   if (s->n_prims <= 0 || !s->prims) return rt::set_error(RT_ERR_INVALID, "scene has no primitives");
   if (s->n_materials <= 0 || !s->materials) return rt::set_error(RT_ERR_INVALID, "scene has no materials");
   if (s->n_textures < 0 || s->n_objects < 0 || s->n_perlins < 0) return rt::set_error(RT_ERR_INVALID, "negative count");
+  if (s->n_materials >= (1 << 19) || s->n_prims >= (1 << 24)) return rt::set_error(RT_ERR_UNSUPPORTED, "too many materials or primitives");
   if (s->n_lights < 0 || s->n_lights > 1) return rt::set_error(RT_ERR_UNSUPPORTED, "n_lights must be 0 or 1");
   if (s->n_lights == 1 && s->lights[0].type != RT_LIGHT_XZ_RECT) return rt::set_error(RT_ERR_UNSUPPORTED, "light type must be RT_LIGHT_XZ_RECT");
   for (int i = 0; i < s->n_textures; ++i) {
@@ -1094,8 +1082,35 @@ int rt_upload_scene(rt_ctx* ctx, const rt_scene* s) {
   free_scene(ctx);
   if ((rc = upload(&ctx->d_scan, scan.data(), scan.size())) != RT_OK) return rc;
   if ((rc = upload(&ctx->d_prims, s->prims, (size_t)s->n_prims)) != RT_OK) return rc;
-  if ((rc = upload(&ctx->d_prim_obj, B.prim_obj.data(), B.prim_obj.size())) != RT_OK) return rc;
-  if ((rc = upload(&ctx->d_objects, s->objects, (size_t)s->n_objects)) != RT_OK) return rc;
+  // One DevPrim per primitive: geometry + the frame it lives in + its material.
+  std::vector<DevPrim> dprims((size_t)s->n_prims);
+  for (int i = 0; i < s->n_prims; ++i) {
+    const rt_prim& q = s->prims[i];
+    const rt_material& m = s->materials[q.material];
+    DevPrim& d = dprims[(size_t)i];
+    std::memset(&d, 0, sizeof(d));
+    d.cos_t = 1.0f;
+    int xform = 0;
+    if (B.prim_obj[(size_t)i] >= 0) {
+      const rt_object& ob = s->objects[B.prim_obj[(size_t)i]];
+      xform = ob.xform & 3;
+      d.sin_t = ob.sin_theta; d.cos_t = ob.cos_theta;
+      d.off[0] = ob.offset[0]; d.off[1] = ob.offset[1]; d.off[2] = ob.offset[2];
+    }
+    d.flags = (q.type & RT_PRIM_TYPE_MASK) | ((q.type & RT_PRIM_FLIP) ? DP_FLIP : 0) | (xform << DP_XFORM_SHIFT) |
+              (m.type << DP_MAT_SHIFT) | (q.material << DP_INDEX_SHIFT);
+    for (int k = 0; k < 5; ++k) d.f[k] = q.f[k];
+    if (m.type == RT_MAT_METAL) {
+      for (int k = 0; k < 3; ++k) d.color[k] = m.albedo[k];
+    } else if (m.texture >= 0 && m.texture < s->n_textures) {
+      const rt_texture& t = s->textures[m.texture];
+      if (t.type == RT_TEX_CONSTANT) for (int k = 0; k < 3; ++k) d.color[k] = t.color[k];
+      else d.flags |= DP_TEXTURED;
+    }
+    d.fuzz = m.fuzz;
+    d.ref_idx = m.ref_idx;
+  }
+  if ((rc = upload(&ctx->d_dprims, dprims.data(), dprims.size())) != RT_OK) return rc;
   if ((rc = upload(&ctx->d_materials, s->materials, (size_t)s->n_materials)) != RT_OK) return rc;
   if ((rc = upload(&ctx->d_textures, s->textures, (size_t)s->n_textures)) != RT_OK) return rc;
   if ((rc = upload(&ctx->d_perlins, s->perlins, (size_t)s->n_perlins)) != RT_OK) return rc;
@@ -1103,15 +1118,13 @@ int rt_upload_scene(rt_ctx* ctx, const rt_scene* s) {
   std::memset(&d, 0, sizeof(d));
   d.scan = (const ScanNode*)ctx->d_scan;
   d.prims = (const rt_prim*)ctx->d_prims;
-  d.prim_obj = (const int*)ctx->d_prim_obj;
+  d.dprims = (const DevPrim*)ctx->d_dprims;
   d.flat = B.any_interior ? 0 : 1;
-  d.objects = (const rt_object*)ctx->d_objects;
   d.materials = (const rt_material*)ctx->d_materials;
   d.textures = (const rt_texture*)ctx->d_textures;
   d.perlins = (const rt_perlin*)ctx->d_perlins;
   d.n_scan = (int)scan.size();
   d.n_prims = s->n_prims;
-  d.n_objects = s->n_objects;
   d.n_lights = s->n_lights;
   if (s->n_lights > 0) d.light = s->lights[0];
   ctx->has_scene = true;
