@@ -477,15 +477,17 @@ struct RenderArgs {
 // render_kernel
 // ---------------------------------------------------------------------------
 template <bool STATS, bool SUMSQ>
-__global__ void __launch_bounds__(256, RT_RENDER_WAVES_PER_SIMD) render_kernel(DevScene S, DevCamera cam, RenderArgs A, float* __restrict__ out_sum,
+__global__ void __launch_bounds__(64, RT_RENDER_WAVES_PER_SIMD) render_kernel(DevScene S, DevCamera cam, RenderArgs A, float* __restrict__ out_sum,
                                                      float* __restrict__ out_sumsq, unsigned long long* __restrict__ stats) {
-  __shared__ float acc[4][6][64];
+  // One single-wave workgroup per work item, so a finished wave frees its slot at
+  // once instead of waiting for the slowest wave of a larger group.
+  __shared__ float acc[1][6][64];
   const int lane = threadIdx.x & 63;
-  const int wib = threadIdx.x >> 6;
+  const int wib = 0;
   // One wave = one work item = (tile, sample chunk).  With more than one chunk
   // each item writes its partial sums to its own slab; reduce_slabs_kernel adds
   // the slabs in a fixed order, so the result does not depend on scheduling.
-  const int item = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wib);
+  const int item = blockIdx.x;
   const int n_tiles = A.tiles_x * A.tiles_y;
   if (item >= n_tiles * A.n_chunks) return;
   const int chunk = item / n_tiles;
@@ -1007,7 +1009,7 @@ int launch_render(rt_ctx* ctx, const rt_camera* cam, const rt_render_params* p, 
   }
   const DevCamera dc = to_dev_camera(cam);
   const int n_items = n_tiles * A.n_chunks;
-  const dim3 grid((n_items + 3) / 4), block(256);
+  const dim3 grid(n_items), block(64);
   if (stats) {
     if (d_sumsq) hipLaunchKernelGGL((render_kernel<true, true>), grid, block, 0, stream, ctx->dev, dc, A, k_sum, k_sumsq, ctx->d_stats);
     else hipLaunchKernelGGL((render_kernel<true, false>), grid, block, 0, stream, ctx->dev, dc, A, k_sum, k_sumsq, ctx->d_stats);
