@@ -204,15 +204,17 @@ typedef struct rt_render_params {
 /* Random numbers.  The reference draws everything from rand::thread_rng()
  * (OS seeded, not replayable).  This ABI fixes a counter-based stream instead:
  * Philox4x32-10 with key (seed low word, seed high word) and counter
- *   (pixel, sample, slot, sub),   pixel = j*nx + i with j counted from the bottom row.
- * slot 0 is the camera sample: words 0,1 jitter u,v (src/main.rs:102-103), words
- * 2,3 the lens-disk candidate of attempt `sub` (src/camera.rs:65-75).
- * slot 1+depth is the path vertex at that depth: sub 0 word 0 top bit is the
- * MixturePDF coin (src/pdf.rs:70), words 1,2 the two draws of whichever
- * generator it picks (src/hitable.rs:259-261 or src/main.rs:241-242), word 3
- * the Dielectric reflect draw (src/material.rs:152); sub 1+m word 0 is the
- * ConstantMedium draw of medium m (src/hitable.rs:582); sub 256+a words 0..2
- * are attempt a of random_in_unit_sphere (src/main.rs:211-221).
+ *   (pixel, sample, depth, sub),   pixel = j*nx + i with j counted from the bottom row.
+ * One call, sub 0, serves a whole path vertex at that depth:
+ *   word 0  (depth 0 only) the pixel jitter of src/main.rs:102-103: its high
+ *           16 bits / 2^16 is added to i, its low 16 bits / 2^16 to j;
+ *   word 1  top bit: the MixturePDF coin (src/pdf.rs:70); bits 30..7 as a 24-bit
+ *           uniform: the Dielectric reflect draw (src/material.rs:152);
+ *   words 2,3  the two draws of whichever generator the coin picks
+ *           (src/hitable.rs:259-261 or src/main.rs:241-242).
+ * sub 1+a at depth 0, words 0,1: attempt a of random_in_unit_disk (src/camera.rs:65-75).
+ * sub 256+a, words 0..2: attempt a of random_in_unit_sphere (src/main.rs:211-221).
+ * sub 4096+m, word 0: the ConstantMedium draw of medium m (src/hitable.rs:582).
  * A 32-bit word x becomes a uniform in [0,1) as (x >> 8) * 2^-24. */
 
 typedef struct rt_stats {

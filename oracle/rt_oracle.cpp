@@ -343,7 +343,7 @@ template <class P> struct World {
     const R dlen = length<P>(r.direction());
     const R distance_inside_boundary = (rec2.t - rec1.t) * dlen;
     uint32_t w[4];
-    smp.draw(1u + (uint32_t)depth, 1u + (uint32_t)ob.medium_index, w);
+    smp.draw((uint32_t)depth, 4096u + (uint32_t)ob.medium_index, w);
     const R xi = Sampler::uniform<R>(w[0]);
     const R hit_distance = -(R(1) / R(ob.density)) * std::log(xi);
     if (hit_distance < distance_inside_boundary) {
@@ -496,7 +496,7 @@ template <class P> struct World {
   Vec random_in_unit_sphere(const Sampler& smp, int depth) const {
     for (uint32_t attempt = 0;; ++attempt) {
       uint32_t w[4];
-      smp.draw(1u + (uint32_t)depth, 256u + attempt, w);
+      smp.draw((uint32_t)depth, 256u + attempt, w);
       const Vec p = scalar<R>(R(2)) * Vec(Sampler::uniform<R>(w[0]), Sampler::uniform<R>(w[1]), Sampler::uniform<R>(w[2])) - scalar<R>(R(1));
       if (squared_length<P>(p) < R(1)) return p;
       if (attempt > 4096) std::abort();
@@ -594,15 +594,15 @@ template <class P> struct World {
       // material.rs:67-74: only the albedo of scatter() is used by color().
       const Vec albedo = texture_value(m.texture, rec.u, rec.v, rec.p);
       uint32_t w[4];
-      smp.draw(1u + (uint32_t)depth, 0u, w);
-      const R xi1 = Sampler::uniform<R>(w[1]), xi2 = Sampler::uniform<R>(w[2]);
+      smp.draw((uint32_t)depth, 0u, w);
+      const R xi1 = Sampler::uniform<R>(w[2]), xi2 = Sampler::uniform<R>(w[3]);
       const ONB uvw = ONB::build_from_w(rec.normal);  // pdf.rs:13-17
       Vec dir;
       R pdf_val;
       if (s->n_lights > 0) {
         const rt_light& lt = s->lights[0];
         // pdf.rs:69-75: gen::<bool>() is the top bit of a fresh 32-bit word.
-        if (w[0] >> 31) dir = light_random(lt, rec.p, xi1, xi2);
+        if (w[1] >> 31) dir = light_random(lt, rec.p, xi1, xi2);
         else dir = uvw.local(random_cosine_direction(xi1, xi2));
         // pdf.rs:65-67, 19-26
         const R cosine = dot<P>(unit<P>(dir), uvw.w);
@@ -649,8 +649,8 @@ template <class P> struct World {
       const bool can_refract = refract(r.direction(), outward_normal, ni_over_nt, refracted);
       reflect_prob = can_refract ? schlick(cosine, ref_idx) : R(1);
       uint32_t w[4];
-      smp.draw(1u + (uint32_t)depth, 0u, w);
-      const Ray<P> scattered = (Sampler::uniform<R>(w[3]) < reflect_prob) ? Ray<P>(rec.p, reflected) : Ray<P>(rec.p, refracted);
+      smp.draw((uint32_t)depth, 0u, w);
+      const Ray<P> scattered = (Sampler::uniform<R>(w[1] << 1) < reflect_prob) ? Ray<P>(rec.p, reflected) : Ray<P>(rec.p, refracted);
       return emitted + color(scattered, depth + 1, smp, prm);  // attenuation (1,1,1)
     }
     if (m.type == RT_MAT_ISOTROPIC) {  // material.rs:217-221
@@ -662,12 +662,12 @@ template <class P> struct World {
   }
 
   // ---- camera.rs:53-75 ----
-  Ray<P> get_ray(const rt_camera& cam, R s_, R t_, const Sampler& smp, const uint32_t first_words[4]) const {
+  Ray<P> get_ray(const rt_camera& cam, R s_, R t_, const Sampler& smp) const {
     Vec p;
-    uint32_t w[4] = {first_words[0], first_words[1], first_words[2], first_words[3]};
     for (uint32_t attempt = 0;; ++attempt) {
-      if (attempt > 0) smp.draw(0u, attempt, w);
-      p = scalar<R>(R(2)) * Vec(Sampler::uniform<R>(w[2]), Sampler::uniform<R>(w[3]), R(0)) - Vec(R(1), R(1), R(0));
+      uint32_t w[4];
+      smp.draw(0u, 1u + attempt, w);
+      p = scalar<R>(R(2)) * Vec(Sampler::uniform<R>(w[0]), Sampler::uniform<R>(w[1]), R(0)) - Vec(R(1), R(1), R(0));
       if (dot<P>(p, p) < R(1)) break;
       if (attempt > 4096) std::abort();
     }
@@ -692,9 +692,9 @@ template <class P> struct World {
     smp.enabled = true;
     uint32_t w[4];
     smp.draw(0u, 0u, w);
-    const R u = (R(i) + Sampler::uniform<R>(w[0])) / R(prm.nx);
-    const R v = (R(j) + Sampler::uniform<R>(w[1])) / R(prm.ny);
-    const Ray<P> r = get_ray(cam, u, v, smp, w);
+    const R u = (R(i) + R(w[0] >> 16) * R(1.0 / 65536.0)) / R(prm.nx);
+    const R v = (R(j) + R(w[0] & 0xffffu) * R(1.0 / 65536.0)) / R(prm.ny);
+    const Ray<P> r = get_ray(cam, u, v, smp);
     cnt.paths++;
     return color(r, 0, smp, prm);
   }
@@ -894,12 +894,12 @@ void orc_camera_ray(const rt_camera* cam, double s, double t, const rt_render_pa
   std::memset(&empty, 0, sizeof(empty));
   if (mode == ORC_F64) {
     World<PolicyF64> world(&empty);
-    const Ray<PolicyF64> r = world.get_ray(*cam, s, t, smp, w);
+    const Ray<PolicyF64> r = world.get_ray(*cam, s, t, smp);
     out_o[0] = r.a.x; out_o[1] = r.a.y; out_o[2] = r.a.z;
     out_d[0] = r.b.x; out_d[1] = r.b.y; out_d[2] = r.b.z;
   } else {
     World<PolicyF32> world(&empty);
-    const Ray<PolicyF32> r = world.get_ray(*cam, (float)s, (float)t, smp, w);
+    const Ray<PolicyF32> r = world.get_ray(*cam, (float)s, (float)t, smp);
     out_o[0] = r.a.x; out_o[1] = r.a.y; out_o[2] = r.a.z;
     out_d[0] = r.b.x; out_d[1] = r.b.y; out_d[2] = r.b.z;
   }

@@ -280,6 +280,38 @@ __device__ __forceinline__ void list_test(const rt_prim* __restrict__ prims, int
   best.prim = take ? loc_prim : best.prim;
 }
 
+// A HitableList of exactly six rects in the order Cuboid::new builds them
+// (hitable.rs:381-416: XY, XY, XZ, XZ, YZ, YZ): the same sequential semantics as
+// list_test, with the three record pairs fetched by three scalar loads up front
+// and no per-primitive dispatch.
+#define LIST_IS_BOX6 0x800000
+template <bool STATS>
+__device__ __forceinline__ void box6_test(const rt_prim* __restrict__ prims, int first, bool lane_on, const RayF& r, float t_min,
+                                          float t_max, Hit& best, Counters& cnt) {
+  const int fu = __builtin_amdgcn_readfirstlane(first);
+  const u32x16 v0 = *(const RT_CONSTANT_AS u32x16*)(prims + fu);
+  const u32x16 v1 = *(const RT_CONSTANT_AS u32x16*)(prims + fu + 2);
+  const u32x16 v2 = *(const RT_CONSTANT_AS u32x16*)(prims + fu + 4);
+  rt_prim q[6];
+  __builtin_memcpy(&q[0], &v0, 64);
+  __builtin_memcpy(&q[2], &v1, 64);
+  __builtin_memcpy(&q[4], &v2, 64);
+  float loc_t = t_max;
+  int loc_prim = -1;
+  float t;
+  bool h;
+  h = rect_test<2, 0, 1>(q[0].f, r, t_min, loc_t, t) & lane_on; loc_t = h ? t : loc_t; loc_prim = h ? fu : loc_prim;
+  h = rect_test<2, 0, 1>(q[1].f, r, t_min, loc_t, t) & lane_on; loc_t = h ? t : loc_t; loc_prim = h ? fu + 1 : loc_prim;
+  h = rect_test<1, 0, 2>(q[2].f, r, t_min, loc_t, t) & lane_on; loc_t = h ? t : loc_t; loc_prim = h ? fu + 2 : loc_prim;
+  h = rect_test<1, 0, 2>(q[3].f, r, t_min, loc_t, t) & lane_on; loc_t = h ? t : loc_t; loc_prim = h ? fu + 3 : loc_prim;
+  h = rect_test<0, 1, 2>(q[4].f, r, t_min, loc_t, t) & lane_on; loc_t = h ? t : loc_t; loc_prim = h ? fu + 4 : loc_prim;
+  h = rect_test<0, 1, 2>(q[5].f, r, t_min, loc_t, t) & lane_on; loc_t = h ? t : loc_t; loc_prim = h ? fu + 5 : loc_prim;
+  if (STATS) cnt.rect_tests += lane_on ? 6u : 0u;
+  const bool take = (loc_prim >= 0) & !(best.t < loc_t);
+  best.t = take ? loc_t : best.t;
+  best.prim = take ? loc_prim : best.prim;
+}
+
 __device__ __forceinline__ int wave_min_i32(int v) {
   for (int off = 32; off > 0; off >>= 1) v = min(v, __shfl_xor(v, off, 64));
   return v;
@@ -330,13 +362,19 @@ __device__ __forceinline__ void scan_range(const DevScene& S, int begin, int end
       best.t = h ? t : best.t;
       best.prim = h ? n.a : best.prim;
     } else if (kind == K_LIST) {
-      if (__ballot(on) != 0ull) list_test<STATS>(S.prims, n.a, n.b, on, r, t_min, t_max, best, cnt);
+      if (__ballot(on) != 0ull) {
+        if (n.b & LIST_IS_BOX6) box6_test<STATS>(S.prims, n.a, on, r, t_min, t_max, best, cnt);
+        else list_test<STATS>(S.prims, n.a, n.b & 0x7fffff, on, r, t_min, t_max, best, cnt);
+      }
     } else if (kind == K_OBJ_LIST || kind == K_OBJ_BVH) {
       if (LEVEL == 0) {
         if (__ballot(on) != 0ull) {
           const RayF q = to_object_frame<true>(r, n.b >> 24, n.f[0], n.f[1], n.f[2], n.f[3], n.f[4]);
           if (STATS) cnt.instance_ops += on;
-          if (kind == K_OBJ_LIST) list_test<STATS>(S.prims, n.a, n.b & 0xffffff, on, q, t_min, t_max, best, cnt);
+          if (kind == K_OBJ_LIST) {
+            if (n.b & LIST_IS_BOX6) box6_test<STATS>(S.prims, n.a, on, q, t_min, t_max, best, cnt);
+            else list_test<STATS>(S.prims, n.a, n.b & 0x7fffff, on, q, t_min, t_max, best, cnt);
+          }
           else scan_range<STATS, false, 1>(S, i + 1, n.skip, on, q, t_min, t_max, best, cnt);
         }
         if (kind == K_OBJ_BVH) {
@@ -512,19 +550,19 @@ __global__ void __launch_bounds__(64, RT_RENDER_WAVES_PER_SIMD) render_kernel(De
   const int pool_size = 64 * s_count;  // a tile of another shard is written as zeros
   int pool_next = 0;
 
-  // Per-lane path state.
-  bool alive = false;
-  RayF ray = make_ray(f3(0, 0, 0), f3(0, 0, 1));
-  F3 thr = f3(0, 0, 0);   // running product of albedo * scattering_pdf / pdf
+  // Per-lane path state.  A lane is either on a path (alive) or waiting for an
+  // item; `fresh` marks a path that has not traced its camera ray yet.
+  bool alive = false, fresh = false;
+  F3 ro = f3(0, 0, 0), rd = f3(0, 0, 1);  // ray to trace next (camera ray or scattered ray)
+  F3 thr = f3(0, 0, 0);                   // running product of albedo * scattering_pdf / pdf
   int depth = 0;
   int pix = 0;            // pixel within the tile
   unsigned pixel_id = 0;  // j*nx + i
   unsigned sample = 0;
 
   for (;;) {
-    // ---- refill dead lanes from the pool (main.rs:101-107) ----
-    // Every lane builds a camera ray for the item it would take; only lanes that
-    // are dead and got an item keep it.
+    // ---- hand (pixel, sample) items to the lanes without a path (main.rs:96-101):
+    // ballot the idle lanes, rank them, take consecutive items from the pool ----
     const unsigned long long need = __ballot(!alive);
     if (need != 0ull && pool_next < pool_size) {
       const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(need >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)need, 0));
@@ -533,45 +571,15 @@ __global__ void __launch_bounds__(64, RT_RENDER_WAVES_PER_SIMD) render_kernel(De
       const bool take = !alive & (k < pool_size);
       const int kk = take ? k : 0;
       const int c_pix = kk & 63;
-      const int s = kk >> 6;
       const int px = tx * 8 + (c_pix & 7);
       const int row = ty * 8 + (c_pix >> 3);  // output row, top first
-      const int j = A.ny - 1 - row;
-      const unsigned c_pixel_id = (unsigned)(j * A.nx + px);
-      const unsigned c_sample = (unsigned)(A.sample_begin + s_first + s);
-      U4 w = philox4x32_10(c_pixel_id, c_sample, 0u, 0u, A.key0, A.key1);
-      const float u = ((float)px + u01(w.x)) * A.inv_nx;
-      const float v = ((float)j + u01(w.y)) * A.inv_ny;
-      // camera.rs:53-75
-      float rdx = 0.0f, rdy = 0.0f;
-      if (cam.lens_radius != 0.0f) {
-        unsigned attempt = 0;
-        bool looking = true;
-        while (__ballot(looking) != 0ull) {
-          const float dx = 2.0f * u01(w.z) - 1.0f, dy = 2.0f * u01(w.w) - 1.0f;
-          const bool ok = looking & (fmaf(dy, dy, dx * dx) < 1.0f);
-          rdx = ok ? cam.lens_radius * dx : rdx;
-          rdy = ok ? cam.lens_radius * dy : rdy;
-          looking &= !ok;
-          ++attempt;
-          w = philox4x32_10(c_pixel_id, c_sample, 0u, attempt, A.key0, A.key1);
-        }
-      }
-      const F3 offset = f3(fmaf(cam.v[0], rdy, cam.u[0] * rdx), fmaf(cam.v[1], rdy, cam.u[1] * rdx), fmaf(cam.v[2], rdy, cam.u[2] * rdx));
-      const F3 org = f3(cam.origin[0] + offset.x, cam.origin[1] + offset.y, cam.origin[2] + offset.z);
-      const F3 dir = f3(fmaf(v, cam.vertical[0], fmaf(u, cam.horizontal[0], cam.llc[0])) - cam.origin[0] - offset.x,
-                        fmaf(v, cam.vertical[1], fmaf(u, cam.horizontal[1], cam.llc[1])) - cam.origin[1] - offset.y,
-                        fmaf(v, cam.vertical[2], fmaf(u, cam.horizontal[2], cam.llc[2])) - cam.origin[2] - offset.z);
-      const RayF fresh = make_ray(org, dir);
       const bool start = take & (px < A.nx) & (row < A.ny);
-      ray.o = sel3(start, fresh.o, ray.o);
-      ray.d = sel3(start, fresh.d, ray.d);
-      ray.inv = sel3(start, fresh.inv, ray.inv);
-      thr = sel3(start, f3(1.0f, 1.0f, 1.0f), thr);
-      depth = start ? 0 : depth;
       pix = start ? c_pix : pix;
-      pixel_id = start ? c_pixel_id : pixel_id;
-      sample = start ? c_sample : sample;
+      pixel_id = start ? (unsigned)((A.ny - 1 - row) * A.nx + px) : pixel_id;
+      sample = start ? (unsigned)(A.sample_begin + s_first + (kk >> 6)) : sample;
+      depth = start ? 0 : depth;
+      thr = sel3(start, f3(1.0f, 1.0f, 1.0f), thr);
+      fresh |= start;
       alive |= start;
       if (STATS) cnt.paths += start;
     }
@@ -579,6 +587,41 @@ __global__ void __launch_bounds__(64, RT_RENDER_WAVES_PER_SIMD) render_kernel(De
       if (pool_next >= pool_size) break;
       continue;
     }
+
+    // ---- the one Philox call of this vertex: counter (pixel, sample, depth, 0) ----
+    const U4 w = philox4x32_10(pixel_id, sample, (unsigned)depth, 0u, A.key0, A.key1);
+
+    // ---- camera ray of the fresh lanes (main.rs:102-105, camera.rs:53-62) ----
+    if (__ballot(fresh) != 0ull) {
+      const int px = tx * 8 + (pix & 7);
+      const int j = A.ny - 1 - (ty * 8 + (pix >> 3));
+      const float u = ((float)px + (float)(w.x >> 16) * (1.0f / 65536.0f)) * A.inv_nx;
+      const float v = ((float)j + (float)(w.x & 0xffffu) * (1.0f / 65536.0f)) * A.inv_ny;
+      float rdx = 0.0f, rdy = 0.0f;
+      if (cam.lens_radius != 0.0f) {
+        // random_in_unit_disk, camera.rs:65-75: attempt a draws counter (pixel, sample, 0, 1+a)
+        unsigned attempt = 0;
+        bool looking = fresh;
+        while (__ballot(looking) != 0ull) {
+          const U4 lw = philox4x32_10(pixel_id, sample, 0u, 1u + attempt, A.key0, A.key1);
+          const float dx = 2.0f * u01(lw.x) - 1.0f, dy = 2.0f * u01(lw.y) - 1.0f;
+          const bool ok = looking & (fmaf(dy, dy, dx * dx) < 1.0f);
+          rdx = ok ? cam.lens_radius * dx : rdx;
+          rdy = ok ? cam.lens_radius * dy : rdy;
+          looking &= !ok;
+          ++attempt;
+        }
+      }
+      const F3 offset = f3(fmaf(cam.v[0], rdy, cam.u[0] * rdx), fmaf(cam.v[1], rdy, cam.u[1] * rdx), fmaf(cam.v[2], rdy, cam.u[2] * rdx));
+      const F3 org = f3(cam.origin[0] + offset.x, cam.origin[1] + offset.y, cam.origin[2] + offset.z);
+      const F3 dir = f3(fmaf(v, cam.vertical[0], fmaf(u, cam.horizontal[0], cam.llc[0])) - cam.origin[0] - offset.x,
+                        fmaf(v, cam.vertical[1], fmaf(u, cam.horizontal[1], cam.llc[1])) - cam.origin[1] - offset.y,
+                        fmaf(v, cam.vertical[2], fmaf(u, cam.horizontal[2], cam.llc[2])) - cam.origin[2] - offset.z);
+      ro = sel3(fresh, org, ro);
+      rd = sel3(fresh, dir, rd);
+      fresh = false;
+    }
+    const RayF ray = make_ray(ro, rd);
 
     // ---- world.hit(r, 0.001, INFINITY), main.rs:166 ----
     if (STATS) cnt.rays += alive;
@@ -609,14 +652,13 @@ __global__ void __launch_bounds__(64, RT_RENDER_WAVES_PER_SIMD) render_kernel(De
     // Lambertian under MixturePDF(HitablePDF(light), CosinePDF(normal)), main.rs:173-197.
     const bool scatters = hit & !is_light & (depth < A.max_depth);
     if (STATS) cnt.shade_events += scatters;
-    const U4 w = philox4x32_10(pixel_id, sample, 1u + (unsigned)depth, 0u, A.key0, A.key1);
-    const float xi1 = u01(w.y), xi2 = u01(w.z);
+    const float xi1 = u01(w.z), xi2 = u01(w.w);
     // onb.rs:10-21
     const F3 ww = unit3(sf.normal);
     const F3 a = fabsf(ww.x) > 0.9f ? f3(0, 1, 0) : f3(1, 0, 0);
     const F3 vv = unit3(cross3(ww, a));
     const F3 uu = cross3(ww, vv);
-    const bool pick_light = (S.n_lights > 0) & ((w.x >> 31) != 0u);
+    const bool pick_light = (S.n_lights > 0) & ((w.y >> 31) != 0u);  // MixturePDF's coin, pdf.rs:70
     // XZRect::random, hitable.rs:256-264
     const F3 dir_light = f3(fmaf(xi1, S.light.f[1] - S.light.f[0], S.light.f[0]) - sf.p.x, S.light.f[4] - sf.p.y,
                             fmaf(xi2, S.light.f[3] - S.light.f[2], S.light.f[2]) - sf.p.z);
@@ -668,10 +710,8 @@ __global__ void __launch_bounds__(64, RT_RENDER_WAVES_PER_SIMD) render_kernel(De
         }
       }
     }
-    const RayF next = make_ray(sf.p, dir);
-    ray.o = sel3(go_on, next.o, ray.o);
-    ray.d = sel3(go_on, next.d, ray.d);
-    ray.inv = sel3(go_on, next.inv, ray.inv);
+    ro = sel3(go_on, sf.p, ro);
+    rd = sel3(go_on, dir, rd);
     thr = sel3(go_on, thr_next, thr);
     depth += go_on ? 1 : 0;
     alive = go_on;
@@ -784,7 +824,7 @@ int validate_scene(const rt_scene* s) {
   if (s->n_prims <= 0 || !s->prims) return rt::set_error(RT_ERR_INVALID, "scene has no primitives");
   if (s->n_materials <= 0 || !s->materials) return rt::set_error(RT_ERR_INVALID, "scene has no materials");
   if (s->n_textures < 0 || s->n_objects < 0 || s->n_perlins < 0) return rt::set_error(RT_ERR_INVALID, "negative count");
-  if (s->n_materials >= (1 << 19) || s->n_prims >= (1 << 24)) return rt::set_error(RT_ERR_UNSUPPORTED, "too many materials or primitives");
+  if (s->n_materials >= (1 << 19) || s->n_prims >= (1 << 23)) return rt::set_error(RT_ERR_UNSUPPORTED, "too many materials or primitives");
   if (s->n_lights < 0 || s->n_lights > 1) return rt::set_error(RT_ERR_UNSUPPORTED, "n_lights must be 0 or 1");
   if (s->n_lights == 1 && s->lights[0].type != RT_LIGHT_XZ_RECT) return rt::set_error(RT_ERR_UNSUPPORTED, "light type must be RT_LIGHT_XZ_RECT");
   for (int i = 0; i < s->n_textures; ++i) {
@@ -853,6 +893,15 @@ struct ScanBuilder {
   bool any_interior;
 };
 
+// True when prims[first, first+count) is six rects in Cuboid::new's order.
+int box6_flag(const rt_scene* s, int first, int count) {
+  static const int order[6] = {RT_PRIM_XY_RECT, RT_PRIM_XY_RECT, RT_PRIM_XZ_RECT, RT_PRIM_XZ_RECT, RT_PRIM_YZ_RECT, RT_PRIM_YZ_RECT};
+  if (count != 6) return 0;
+  for (int k = 0; k < 6; ++k)
+    if ((s->prims[first + k].type & RT_PRIM_TYPE_MASK) != order[k]) return 0;
+  return LIST_IS_BOX6;
+}
+
 ScanNode box_node(const rt_node& n) {
   ScanNode sn;
   std::memset(&sn, 0, sizeof(sn));
@@ -898,7 +947,7 @@ int build_scan(ScanBuilder* B, int idx, bool in_sub, bool collapsed, bool tree_r
     } else {
       sn.kind = K_LIST;
       sn.a = ref;
-      sn.b = n.right;
+      sn.b = n.right | box6_flag(s, ref, n.right);
     }
     sn.skip = (int)B->out.size() + 1;
     B->out.push_back(sn);
@@ -915,7 +964,7 @@ int build_scan(ScanBuilder* B, int idx, bool in_sub, bool collapsed, bool tree_r
     for (int k = ob.first; k < ob.first + ob.count; ++k) B->prim_obj[k] = ref;
     sn.kind = K_OBJ_LIST;
     sn.a = ob.first;
-    sn.b = ob.count | (ob.xform << 24);
+    sn.b = ob.count | box6_flag(s, ob.first, ob.count) | (ob.xform << 24);
     sn.skip = (int)at + 1;
     B->out.push_back(sn);
     return RT_OK;
