@@ -281,31 +281,37 @@ __device__ __forceinline__ void list_test(const rt_prim* __restrict__ prims, int
 }
 
 // A HitableList of exactly six rects in the order Cuboid::new builds them
-// (hitable.rs:381-416: XY, XY, XZ, XZ, YZ, YZ): the same sequential semantics as
-// list_test, with the three record pairs fetched by three scalar loads up front
-// and no per-primitive dispatch.
+// (hitable.rs:381-416: XY, XY, XZ, XZ, YZ, YZ) whose pairs share their in-plane
+// bounds: the same sequential semantics as list_test, from an 18-float record
+// (per pair a0,a1,b0,b1,k_first,k_second) stored in the two scan slots that
+// follow the node, fetched by two scalar loads, with no per-primitive dispatch.
 #define LIST_IS_BOX6 0x800000
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+template <int C, int A, int B>
+__device__ __forceinline__ void box_pair(const float* g, int prim0, bool lane_on, const RayF& r, float t_min, float& loc_t, int& loc_prim) {
+  float f[5] = {g[0], g[1], g[2], g[3], g[4]};
+  float t;
+  bool h = rect_test<C, A, B>(f, r, t_min, loc_t, t) & lane_on;
+  loc_t = h ? t : loc_t;
+  loc_prim = h ? prim0 : loc_prim;
+  f[4] = g[5];
+  h = rect_test<C, A, B>(f, r, t_min, loc_t, t) & lane_on;
+  loc_t = h ? t : loc_t;
+  loc_prim = h ? prim0 + 1 : loc_prim;
+}
 template <bool STATS>
-__device__ __forceinline__ void box6_test(const rt_prim* __restrict__ prims, int first, bool lane_on, const RayF& r, float t_min,
+__device__ __forceinline__ void box6_test(const ScanNode* __restrict__ scan, int node, int first, bool lane_on, const RayF& r, float t_min,
                                           float t_max, Hit& best, Counters& cnt) {
-  const int fu = __builtin_amdgcn_readfirstlane(first);
-  const u32x16 v0 = *(const RT_CONSTANT_AS u32x16*)(prims + fu);
-  const u32x16 v1 = *(const RT_CONSTANT_AS u32x16*)(prims + fu + 2);
-  const u32x16 v2 = *(const RT_CONSTANT_AS u32x16*)(prims + fu + 4);
-  rt_prim q[6];
-  __builtin_memcpy(&q[0], &v0, 64);
-  __builtin_memcpy(&q[2], &v1, 64);
-  __builtin_memcpy(&q[4], &v2, 64);
+  const u32x16 v0 = *(const RT_CONSTANT_AS u32x16*)(scan + node + 1);
+  const u32x2 v1 = *(const RT_CONSTANT_AS u32x2*)(scan + node + 2);
+  float g[18];
+  __builtin_memcpy(&g[0], &v0, 64);
+  __builtin_memcpy(&g[16], &v1, 8);
   float loc_t = t_max;
   int loc_prim = -1;
-  float t;
-  bool h;
-  h = rect_test<2, 0, 1>(q[0].f, r, t_min, loc_t, t) & lane_on; loc_t = h ? t : loc_t; loc_prim = h ? fu : loc_prim;
-  h = rect_test<2, 0, 1>(q[1].f, r, t_min, loc_t, t) & lane_on; loc_t = h ? t : loc_t; loc_prim = h ? fu + 1 : loc_prim;
-  h = rect_test<1, 0, 2>(q[2].f, r, t_min, loc_t, t) & lane_on; loc_t = h ? t : loc_t; loc_prim = h ? fu + 2 : loc_prim;
-  h = rect_test<1, 0, 2>(q[3].f, r, t_min, loc_t, t) & lane_on; loc_t = h ? t : loc_t; loc_prim = h ? fu + 3 : loc_prim;
-  h = rect_test<0, 1, 2>(q[4].f, r, t_min, loc_t, t) & lane_on; loc_t = h ? t : loc_t; loc_prim = h ? fu + 4 : loc_prim;
-  h = rect_test<0, 1, 2>(q[5].f, r, t_min, loc_t, t) & lane_on; loc_t = h ? t : loc_t; loc_prim = h ? fu + 5 : loc_prim;
+  box_pair<2, 0, 1>(&g[0], first, lane_on, r, t_min, loc_t, loc_prim);
+  box_pair<1, 0, 2>(&g[6], first + 2, lane_on, r, t_min, loc_t, loc_prim);
+  box_pair<0, 1, 2>(&g[12], first + 4, lane_on, r, t_min, loc_t, loc_prim);
   if (STATS) cnt.rect_tests += lane_on ? 6u : 0u;
   const bool take = (loc_prim >= 0) & !(best.t < loc_t);
   best.t = take ? loc_t : best.t;
@@ -363,7 +369,7 @@ __device__ __forceinline__ void scan_range(const DevScene& S, int begin, int end
       best.prim = h ? n.a : best.prim;
     } else if (kind == K_LIST) {
       if (__ballot(on) != 0ull) {
-        if (n.b & LIST_IS_BOX6) box6_test<STATS>(S.prims, n.a, on, r, t_min, t_max, best, cnt);
+        if (n.b & LIST_IS_BOX6) box6_test<STATS>(S.scan, i, n.a, on, r, t_min, t_max, best, cnt);
         else list_test<STATS>(S.prims, n.a, n.b & 0x7fffff, on, r, t_min, t_max, best, cnt);
       }
     } else if (kind == K_OBJ_LIST || kind == K_OBJ_BVH) {
@@ -372,10 +378,10 @@ __device__ __forceinline__ void scan_range(const DevScene& S, int begin, int end
           const RayF q = to_object_frame<true>(r, n.b >> 24, n.f[0], n.f[1], n.f[2], n.f[3], n.f[4]);
           if (STATS) cnt.instance_ops += on;
           if (kind == K_OBJ_LIST) {
-            if (n.b & LIST_IS_BOX6) box6_test<STATS>(S.prims, n.a, on, q, t_min, t_max, best, cnt);
+            if (n.b & LIST_IS_BOX6) box6_test<STATS>(S.scan, i, n.a, on, q, t_min, t_max, best, cnt);
             else list_test<STATS>(S.prims, n.a, n.b & 0x7fffff, on, q, t_min, t_max, best, cnt);
           }
-          else scan_range<STATS, false, 1>(S, i + 1, n.skip, on, q, t_min, t_max, best, cnt);
+          else if (!FLAT) scan_range<STATS, false, 1>(S, i + 1, n.skip, on, q, t_min, t_max, best, cnt);
         }
         if (kind == K_OBJ_BVH) {
           i = n.skip;
@@ -383,18 +389,20 @@ __device__ __forceinline__ void scan_range(const DevScene& S, int begin, int end
         }
       }
     }
-    ++i;
+    // A leaf's skip is the next node (past any extension slots); an interior node's first child follows it.
+    i = (kind == K_INTERIOR) ? i + 1 : n.skip;
   }
 }
 
 // Nearest hit of BvhNode::hit (bvh.rs:197-228).  Must be called by all 64 lanes.
-template <bool STATS>
+// FLAT is chosen by the host per scene (DevScene::flat): each variant is its own
+// kernel so the register allocator only sees the code that scene can reach.
+template <bool STATS, bool FLAT>
 __device__ __forceinline__ Hit trace_scan(const DevScene& S, bool active, const RayF& w, float t_min, float t_max, Counters& cnt) {
   Hit best;
   best.t = t_max;
   best.prim = -1;
-  if (S.flat) scan_range<STATS, true, 0>(S, 0, S.n_scan, active, w, t_min, t_max, best, cnt);
-  else scan_range<STATS, false, 0>(S, 0, S.n_scan, active, w, t_min, t_max, best, cnt);
+  scan_range<STATS, FLAT, 0>(S, 0, S.n_scan, active, w, t_min, t_max, best, cnt);
   return best;
 }
 
@@ -430,6 +438,7 @@ __device__ __forceinline__ Surface finalize_hit(const DevPrim& q, const RayF& w,
 // ---------------------------------------------------------------------------
 // trace_kernel
 // ---------------------------------------------------------------------------
+template <bool FLAT>
 __global__ void __launch_bounds__(256) trace_kernel(DevScene S, const float* __restrict__ o, const float* __restrict__ d, size_t n,
                                                     float t_min, float t_max, int* __restrict__ prim_id, float* __restrict__ t_out,
                                                     float* __restrict__ normal, float* __restrict__ p_out) {
@@ -441,7 +450,7 @@ __global__ void __launch_bounds__(256) trace_kernel(DevScene S, const float* __r
     const size_t at = active ? idx : 0;
     const RayF w = make_ray(f3(o[3 * at], o[3 * at + 1], o[3 * at + 2]), f3(d[3 * at], d[3 * at + 1], d[3 * at + 2]));
     Counters cnt;
-    const Hit h = trace_scan<false>(S, active, w, t_min, t_max, cnt);
+    const Hit h = trace_scan<false, FLAT>(S, active, w, t_min, t_max, cnt);
     if (active) {
       prim_id[idx] = h.prim;
       t_out[idx] = h.prim >= 0 ? h.t : 0.0f;
@@ -514,7 +523,7 @@ struct RenderArgs {
 // ---------------------------------------------------------------------------
 // render_kernel
 // ---------------------------------------------------------------------------
-template <bool STATS, bool SUMSQ>
+template <bool STATS, bool SUMSQ, bool FLAT>
 __global__ void __launch_bounds__(64, RT_RENDER_WAVES_PER_SIMD) render_kernel(DevScene S, DevCamera cam, RenderArgs A, float* __restrict__ out_sum,
                                                      float* __restrict__ out_sumsq, unsigned long long* __restrict__ stats) {
   // One single-wave workgroup per work item, so a finished wave frees its slot at
@@ -625,7 +634,7 @@ __global__ void __launch_bounds__(64, RT_RENDER_WAVES_PER_SIMD) render_kernel(De
 
     // ---- world.hit(r, 0.001, INFINITY), main.rs:166 ----
     if (STATS) cnt.rays += alive;
-    const Hit h = trace_scan<STATS>(S, alive, ray, A.t_min, INFINITY, cnt);
+    const Hit h = trace_scan<STATS, FLAT>(S, alive, ray, A.t_min, INFINITY, cnt);
 
     // ---- color(), main.rs:165-209, one vertex; every lane runs it, dead lanes and
     // misses on primitive 0 with their results masked ----
@@ -899,7 +908,27 @@ int box6_flag(const rt_scene* s, int first, int count) {
   if (count != 6) return 0;
   for (int k = 0; k < 6; ++k)
     if ((s->prims[first + k].type & RT_PRIM_TYPE_MASK) != order[k]) return 0;
+  for (int k = 0; k < 6; k += 2)
+    for (int c = 0; c < 4; ++c)
+      if (s->prims[first + k].f[c] != s->prims[first + k + 1].f[c]) return 0;
   return LIST_IS_BOX6;
+}
+
+// The two extension slots of a six-rect box: per pair a0,a1,b0,b1,k_first,k_second.
+void push_box6(const rt_scene* s, int first, std::vector<ScanNode>* out) {
+  float g[32];
+  std::memset(g, 0, sizeof(g));
+  for (int pair = 0; pair < 3; ++pair) {
+    const rt_prim& q0 = s->prims[first + 2 * pair];
+    const rt_prim& q1 = s->prims[first + 2 * pair + 1];
+    for (int c = 0; c < 4; ++c) g[6 * pair + c] = q0.f[c];
+    g[6 * pair + 4] = q0.f[4];
+    g[6 * pair + 5] = q1.f[4];
+  }
+  ScanNode ext[2];
+  std::memcpy(ext, g, sizeof(ext));
+  out->push_back(ext[0]);
+  out->push_back(ext[1]);
 }
 
 ScanNode box_node(const rt_node& n) {
@@ -949,8 +978,10 @@ int build_scan(ScanBuilder* B, int idx, bool in_sub, bool collapsed, bool tree_r
       sn.a = ref;
       sn.b = n.right | box6_flag(s, ref, n.right);
     }
-    sn.skip = (int)B->out.size() + 1;
+    const bool box6 = sn.kind == K_LIST && (sn.b & LIST_IS_BOX6);
+    sn.skip = (int)B->out.size() + (box6 ? 3 : 1);
     B->out.push_back(sn);
+    if (box6) push_box6(s, ref, &B->out);
     return RT_OK;
   }
   if (n.right < 0) return rt::set_error(RT_ERR_INVALID, "leaf with negative count");
@@ -965,8 +996,9 @@ int build_scan(ScanBuilder* B, int idx, bool in_sub, bool collapsed, bool tree_r
     sn.kind = K_OBJ_LIST;
     sn.a = ob.first;
     sn.b = ob.count | box6_flag(s, ob.first, ob.count) | (ob.xform << 24);
-    sn.skip = (int)at + 1;
+    sn.skip = (int)at + ((sn.b & LIST_IS_BOX6) ? 3 : 1);
     B->out.push_back(sn);
+    if (sn.b & LIST_IS_BOX6) push_box6(s, ob.first, &B->out);
     return RT_OK;
   }
   // RT_OBJ_BVH: the sub-tree follows inline, in the object's frame.
@@ -1059,13 +1091,12 @@ int launch_render(rt_ctx* ctx, const rt_camera* cam, const rt_render_params* p, 
   const DevCamera dc = to_dev_camera(cam);
   const int n_items = n_tiles * A.n_chunks;
   const dim3 grid(n_items), block(64);
-  if (stats) {
-    if (d_sumsq) hipLaunchKernelGGL((render_kernel<true, true>), grid, block, 0, stream, ctx->dev, dc, A, k_sum, k_sumsq, ctx->d_stats);
-    else hipLaunchKernelGGL((render_kernel<true, false>), grid, block, 0, stream, ctx->dev, dc, A, k_sum, k_sumsq, ctx->d_stats);
-  } else {
-    if (d_sumsq) hipLaunchKernelGGL((render_kernel<false, true>), grid, block, 0, stream, ctx->dev, dc, A, k_sum, k_sumsq, ctx->d_stats);
-    else hipLaunchKernelGGL((render_kernel<false, false>), grid, block, 0, stream, ctx->dev, dc, A, k_sum, k_sumsq, ctx->d_stats);
-  }
+  typedef void (*RenderFn)(DevScene, DevCamera, RenderArgs, float*, float*, unsigned long long*);
+  static const RenderFn table[8] = {
+      render_kernel<false, false, false>, render_kernel<false, false, true>, render_kernel<false, true, false>, render_kernel<false, true, true>,
+      render_kernel<true, false, false>,  render_kernel<true, false, true>,  render_kernel<true, true, false>,  render_kernel<true, true, true>};
+  const RenderFn fn = table[(stats ? 4 : 0) | (d_sumsq ? 2 : 0) | (ctx->dev.flat ? 1 : 0)];
+  hipLaunchKernelGGL(fn, grid, block, 0, stream, ctx->dev, dc, A, k_sum, k_sumsq, ctx->d_stats);
   HIP_TRY(hipGetLastError());
   if (A.n_chunks > 1) {
     const size_t n4 = n / 4;
@@ -1251,7 +1282,8 @@ int rt_trace_closest(rt_ctx* ctx, const float* o, const float* d, size_t n, floa
   if (e == hipSuccess) {
     size_t blocks = (n + 255) / 256;
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(trace_kernel, dim3((unsigned)blocks), dim3(256), 0, 0, ctx->dev, d_o, d_d, n, t_min, t_max, d_id, d_t, d_n, d_p);
+    if (ctx->dev.flat) hipLaunchKernelGGL(trace_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, 0, ctx->dev, d_o, d_d, n, t_min, t_max, d_id, d_t, d_n, d_p);
+    else hipLaunchKernelGGL(trace_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, 0, ctx->dev, d_o, d_d, n, t_min, t_max, d_id, d_t, d_n, d_p);
     e = hipGetLastError();
   }
   if (e == hipSuccess) e = hipDeviceSynchronize();
