@@ -49,7 +49,9 @@ enum {
   K_SPHERE = 4,    // leaf holding one sphere: f = cx,cy,cz,r ; a = prim index
   K_LIST = 5,      // leaf holding prims[a, a+b) as a HitableList in the node's own frame
   K_OBJ_LIST = 6,  // Translate(RotateY(list)): f = sin,cos,ox,oy,oz ; xform ; prims[a, a+b)
-  K_OBJ_BVH = 7    // Translate(RotateY(BvhNode)): same f/xform; the sub-tree's nodes follow up to skip
+  K_OBJ_BVH = 7,   // Translate(RotateY(BvhNode)): same f/xform; the sub-tree's nodes follow up to skip
+  K_MEDIUM = 8     // ConstantMedium over Translate(RotateY(list)): as K_OBJ_LIST; the last extension slot holds
+                   // density, medium ordinal, DevPrim index
 };
 
 // One node of the depth-first ("scan") layout, 64 bytes = one s_load_dwordx16.
@@ -68,11 +70,12 @@ struct ScanNode {
 // Everything the path loop needs to know about the primitive it hit, gathered
 // with one 64-byte read: geometry, the transform of the object it lives in, and
 // its material with a constant texture already resolved to a colour.
-#define DP_TYPE_MASK 0x3
-#define DP_FLIP 0x4
-#define DP_XFORM_SHIFT 3   // 2 bits: RT_XFORM_*
-#define DP_MAT_SHIFT 5     // 3 bits: RT_MAT_*
-#define DP_TEXTURED 0x100  // the colour must come from Texture::value (checker / noise)
+#define DP_TYPE_MASK 0x7   // RT_PRIM_* or DP_TYPE_MEDIUM
+#define DP_TYPE_MEDIUM 4   // a ConstantMedium's scattering point: p = ray(t), normal (1,0,0) (hitable.rs:586-593)
+#define DP_FLIP 0x8
+#define DP_XFORM_SHIFT 4   // 2 bits: RT_XFORM_*
+#define DP_MAT_SHIFT 6     // 3 bits: RT_MAT_*
+#define DP_TEXTURED 0x200  // the colour must come from Texture::value (checker / noise)
 #define DP_INDEX_SHIFT 12  // material index
 struct DevPrim {
   int flags;
@@ -99,6 +102,8 @@ struct DevScene {
   const rt_texture* textures;
   const rt_perlin* perlins;
   int n_scan, n_prims, n_lights;
+  int mat_mask;  // bit RT_MAT_* set when a primitive or medium uses that material
+  int textured;  // some material needs Texture::value (checker / noise)
   int flat;  // 1: the scan array holds leaves only (every skip is the next index)
   rt_light light;
 };
@@ -162,6 +167,38 @@ __device__ __forceinline__ rt_prim load_prim_uniform(const rt_prim* base, int i)
   __builtin_memcpy(&q, &v, sizeof(q));
   return q;
 }
+
+// ---------------------------------------------------------------------------
+// Philox4x32-10 (Salmon et al., SC'11) and the stream layout of rt_abi.h
+// ---------------------------------------------------------------------------
+struct U4 {
+  unsigned x, y, z, w;
+};
+__device__ __forceinline__ U4 philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1) {
+  const unsigned M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+  for (int round = 0; round < 10; ++round) {
+    const unsigned long long p0 = (unsigned long long)M0 * c0;
+    const unsigned long long p1 = (unsigned long long)M1 * c2;
+    const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0;
+    const unsigned n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1;
+    c1 = (unsigned)p1;
+    c3 = (unsigned)p0;
+    c0 = n0;
+    c2 = n2;
+    k0 += W0;
+    k1 += W1;
+  }
+  U4 r;
+  r.x = c0; r.y = c1; r.z = c2; r.w = c3;
+  return r;
+}
+__device__ __forceinline__ float u01(unsigned x) { return (float)(x >> 8) * (1.0f / 16777216.0f); }
+
+// What a ConstantMedium needs to draw its random number inside the traversal.
+struct PathRng {
+  unsigned pixel, sample, depth, key0, key1;
+};
 
 struct Counters {
   unsigned rays, hits, node_tests, rect_tests, sphere_tests, instance_ops, shade_events, light_tests, paths;
@@ -327,9 +364,9 @@ __device__ __forceinline__ int wave_min_i32(int v) {
 // wave taking part in the control flow.  LEVEL 0 is the world frame; a K_OBJ_BVH
 // node re-enters at LEVEL 1 with the ray moved into the object's frame.  FLAT
 // means every node is a leaf, so no lane ever skips ahead.
-template <bool STATS, bool FLAT, int LEVEL>
+template <bool STATS, bool FLAT, bool MEDIA, int LEVEL>
 __device__ __forceinline__ void scan_range(const DevScene& S, int begin, int end, bool active, const RayF& r, float t_min, float t_max,
-                                           Hit& best, Counters& cnt) {
+                                           const PathRng& rng, Hit& best, Counters& cnt) {
   const Signs sg = ray_signs(r);
   int lane_next = active ? begin : 0x7fffffff;
   int i = begin;
@@ -381,12 +418,41 @@ __device__ __forceinline__ void scan_range(const DevScene& S, int begin, int end
             if (n.b & LIST_IS_BOX6) box6_test<STATS>(S.scan, i, n.a, on, q, t_min, t_max, best, cnt);
             else list_test<STATS>(S.prims, n.a, n.b & 0x7fffff, on, q, t_min, t_max, best, cnt);
           }
-          else if (!FLAT) scan_range<STATS, false, 1>(S, i + 1, n.skip, on, q, t_min, t_max, best, cnt);
+          else if (!FLAT) scan_range<STATS, false, false, 1>(S, i + 1, n.skip, on, q, t_min, t_max, rng, best, cnt);
         }
         if (kind == K_OBJ_BVH) {
           i = n.skip;
           continue;
         }
+      }
+    }
+    else if (MEDIA && kind == K_MEDIUM && LEVEL == 0) {
+      // ConstantMedium::hit, hitable.rs:560-598 (commented out in the reference).
+      if (__ballot(on) != 0ull) {
+        const RayF q = to_object_frame<true>(r, n.b >> 24, n.f[0], n.f[1], n.f[2], n.f[3], n.f[4]);
+        const bool box6 = (n.b & LIST_IS_BOX6) != 0;
+        const ScanNode ext = load_node(S.scan, n.skip - 1);  // density, ordinal, DevPrim index
+        Hit b1, b2;
+        b1.t = 3.402823466e+38f; b1.prim = -1;
+        if (box6) box6_test<STATS>(S.scan, i, n.a, on, q, -3.402823466e+38f, 3.402823466e+38f, b1, cnt);
+        else list_test<STATS>(S.prims, n.a, n.b & 0x7fffff, on, q, -3.402823466e+38f, 3.402823466e+38f, b1, cnt);
+        b2.t = 3.402823466e+38f; b2.prim = -1;
+        if (box6) box6_test<STATS>(S.scan, i, n.a, on, q, b1.t + 0.0001f, 3.402823466e+38f, b2, cnt);
+        else list_test<STATS>(S.prims, n.a, n.b & 0x7fffff, on, q, b1.t + 0.0001f, 3.402823466e+38f, b2, cnt);
+        float t1 = b1.t, t2 = b2.t;
+        t1 = t1 < t_min ? t_min : t1;
+        t2 = t2 > t_max ? t_max : t2;
+        bool ok = on & (b1.prim >= 0) & (b2.prim >= 0) & !(t1 >= t2);
+        t1 = t1 < 0.0f ? 0.0f : t1;
+        const float dlen = sqrtf(dot3(r.d, r.d));
+        const float inside = (t2 - t1) * dlen;
+        const U4 mw = philox4x32_10(rng.pixel, rng.sample, rng.depth, 4096u + (unsigned)ext.a, rng.key0, rng.key1);
+        const float hit_distance = -(1.0f / ext.f[0]) * __logf(u01(mw.x));
+        const float t = t1 + hit_distance / dlen;
+        ok &= (hit_distance < inside) & !(best.t < t);
+        best.t = ok ? t : best.t;
+        best.prim = ok ? ext.b : best.prim;
+        if (STATS) cnt.instance_ops += on;
       }
     }
     // A leaf's skip is the next node (past any extension slots); an interior node's first child follows it.
@@ -397,12 +463,13 @@ __device__ __forceinline__ void scan_range(const DevScene& S, int begin, int end
 // Nearest hit of BvhNode::hit (bvh.rs:197-228).  Must be called by all 64 lanes.
 // FLAT is chosen by the host per scene (DevScene::flat): each variant is its own
 // kernel so the register allocator only sees the code that scene can reach.
-template <bool STATS, bool FLAT>
-__device__ __forceinline__ Hit trace_scan(const DevScene& S, bool active, const RayF& w, float t_min, float t_max, Counters& cnt) {
+template <bool STATS, bool FLAT, bool MEDIA>
+__device__ __forceinline__ Hit trace_scan(const DevScene& S, bool active, const RayF& w, float t_min, float t_max, const PathRng& rng,
+                                          Counters& cnt) {
   Hit best;
   best.t = t_max;
   best.prim = -1;
-  scan_range<STATS, FLAT, 0>(S, 0, S.n_scan, active, w, t_min, t_max, best, cnt);
+  scan_range<STATS, FLAT, MEDIA, 0>(S, 0, S.n_scan, active, w, t_min, t_max, rng, best, cnt);
   return best;
 }
 
@@ -423,6 +490,7 @@ __device__ __forceinline__ Surface finalize_hit(const DevPrim& q, const RayF& w,
   const float sgn = (q.flags & DP_FLIP) ? -1.0f : 1.0f;
   F3 nrm = f3(type == RT_PRIM_YZ_RECT ? sgn : 0.0f, type == RT_PRIM_XZ_RECT ? sgn : 0.0f, type == RT_PRIM_XY_RECT ? sgn : 0.0f);
   nrm = sel3(type == RT_PRIM_SPHERE, f3((p.x - q.f[0]) * inv_r, (p.y - q.f[1]) * inv_r, (p.z - q.f[2]) * inv_r), nrm);
+  nrm = sel3(type == DP_TYPE_MEDIUM, f3(1.0f, 0.0f, 0.0f), nrm);
   const bool ro = (xform & RT_XFORM_ROTATE_Y) != 0, tr = (xform & RT_XFORM_TRANSLATE) != 0;
   const F3 pl = p, nl = nrm;
   p.x = ro ? fmaf(q.cos_t, pl.x, q.sin_t * pl.z) : pl.x;
@@ -450,7 +518,8 @@ __global__ void __launch_bounds__(256) trace_kernel(DevScene S, const float* __r
     const size_t at = active ? idx : 0;
     const RayF w = make_ray(f3(o[3 * at], o[3 * at + 1], o[3 * at + 2]), f3(d[3 * at], d[3 * at + 1], d[3 * at + 2]));
     Counters cnt;
-    const Hit h = trace_scan<false, FLAT>(S, active, w, t_min, t_max, cnt);
+    PathRng rng = {0u, 0u, 0u, 0u, 0u};  // a deterministic query takes no random numbers: media are skipped
+    const Hit h = trace_scan<false, FLAT, false>(S, active, w, t_min, t_max, rng, cnt);
     if (active) {
       prim_id[idx] = h.prim;
       t_out[idx] = h.prim >= 0 ? h.t : 0.0f;
@@ -466,33 +535,6 @@ __global__ void __launch_bounds__(256) trace_kernel(DevScene S, const float* __r
   }
 }
 
-// ---------------------------------------------------------------------------
-// Philox4x32-10 (Salmon et al., SC'11) and the stream layout of rt_abi.h
-// ---------------------------------------------------------------------------
-struct U4 {
-  unsigned x, y, z, w;
-};
-__device__ __forceinline__ U4 philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1) {
-  const unsigned M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
-#pragma unroll
-  for (int round = 0; round < 10; ++round) {
-    const unsigned long long p0 = (unsigned long long)M0 * c0;
-    const unsigned long long p1 = (unsigned long long)M1 * c2;
-    const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0;
-    const unsigned n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1;
-    c1 = (unsigned)p1;
-    c3 = (unsigned)p0;
-    c0 = n0;
-    c2 = n2;
-    k0 += W0;
-    k1 += W1;
-  }
-  U4 r;
-  r.x = c0; r.y = c1; r.z = c2; r.w = c3;
-  return r;
-}
-__device__ __forceinline__ float u01(unsigned x) { return (float)(x >> 8) * (1.0f / 16777216.0f); }
-
 // Shading-side helpers.  Nothing from here on is compared bit for bit with the
 // CPU (Monte Carlo sums are checked statistically), so the hardware's 1-ulp
 // reciprocal, reciprocal square root and square root are used directly.
@@ -503,6 +545,82 @@ __device__ __forceinline__ F3 cross3(F3 a, F3 b) {  // vec3.rs:180-186
   return f3(fmaf(a.y, b.z, -(a.z * b.y)), fmaf(a.z, b.x, -(a.x * b.z)), fmaf(a.x, b.y, -(a.y * b.x)));
 }
 __device__ __forceinline__ F3 unit3(F3 a) { return a * fast_rsq(dot3(a, a)); }  // vec3.rs:188-190
+
+// sin(x) through v_sin_f32, which takes turns and needs its argument reduced
+// first.  At |x| of a few thousand the result is good to about 1e-3, which moves
+// a checker boundary by less than a thousandth of a cell.
+__device__ __forceinline__ float fast_sin(float x) {
+  const float turns = x * 0.15915494309189533577f;
+  return __builtin_amdgcn_sinf(turns - floorf(turns));
+}
+
+// `f64 as usize` of perlin.rs:34-36 (saturating, negatives and NaN to 0), reduced
+// mod 256 the way the wrapping `(i + di) & 255` of perlin.rs:43-45 sees it.
+__device__ __forceinline__ unsigned perlin_cell(float f) {
+  if (!(f > 0.0f)) return 0u;
+  if (f >= 18446744073709551616.0f) return 255u;  // usize::MAX
+  if (f >= 4294967296.0f) return 0u;               // a multiple of 512 at this magnitude
+  return (unsigned)f & 255u;
+}
+
+// Perlin::noise (perlin.rs:29-50) with perlin_interpolate (perlin.rs:102-124).
+__device__ float perlin_noise(const rt_perlin* __restrict__ pn, F3 p) {
+  const float fx = floorf(p.x), fy = floorf(p.y), fz = floorf(p.z);
+  const float u = p.x - fx, v = p.y - fy, w = p.z - fz;
+  const unsigned i = perlin_cell(fx), j = perlin_cell(fy), k = perlin_cell(fz);
+  const float uu = u * u * (3.0f - 2.0f * u);
+  const float vv = v * v * (3.0f - 2.0f * v);
+  const float ww = w * w * (3.0f - 2.0f * w);
+  float accum = 0.0f;
+#pragma unroll
+  for (int di = 0; di < 2; ++di)
+#pragma unroll
+    for (int dj = 0; dj < 2; ++dj)
+#pragma unroll
+      for (int dk = 0; dk < 2; ++dk) {
+        const int idx = pn->perm_x[(i + di) & 255u] ^ pn->perm_y[(j + dj) & 255u] ^ pn->perm_z[(k + dk) & 255u];
+        const float* c = pn->ranvec[idx & 255];
+        const float wi = di ? uu : 1.0f - uu, wj = dj ? vv : 1.0f - vv, wk = dk ? ww : 1.0f - ww;
+        accum += wi * wj * wk * (c[0] * (u - (float)di) + c[1] * (v - (float)dj) + c[2] * (w - (float)dk));
+      }
+  return accum;
+}
+
+// Perlin::turb (perlin.rs:52-63).
+__device__ float perlin_turb(const rt_perlin* __restrict__ pn, F3 p, int depth) {
+  float accum = 0.0f, weight = 1.0f;
+  for (int o = 0; o < depth; ++o) {
+    accum += weight * perlin_noise(pn, p);
+    weight *= 0.5f;
+    p = p * 2.0f;
+  }
+  return fabsf(accum);
+}
+
+// Texture::value (texture.rs:22-35).  A checker of checkers is followed down
+// (the source recurses); eight levels are more than any scene here nests.
+__device__ F3 texture_value(const DevScene& S, int tex, F3 p) {
+  for (int level = 0; level < 8; ++level) {
+    const rt_texture t = S.textures[tex];
+    if (t.type == RT_TEX_CHECKER) {
+      const float sines = fast_sin(10.0f * p.x) * fast_sin(10.0f * p.y) * fast_sin(10.0f * p.z);
+      tex = sines < 0.0f ? t.odd : t.even;
+      continue;
+    }
+    if (t.type == RT_TEX_NOISE) {
+      const float g = 0.5f * (1.0f + fast_sin(t.scale * p.z + 10.0f * perlin_turb(S.perlins + t.perlin, p, 7)));
+      return f3(g, g, g);
+    }
+    return f3(t.color[0], t.color[1], t.color[2]);
+  }
+  return f3(0, 0, 0);
+}
+
+// reflect / refract / schlick of material.rs:162-180 (commented out in the reference).
+__device__ __forceinline__ F3 reflect3(F3 v, F3 n) {
+  const float k = 2.0f * dot3(v, n);
+  return f3(v.x - k * n.x, v.y - k * n.y, v.z - k * n.z);
+}
 
 struct RenderArgs {
   int nx, ny, spp, sample_begin, max_depth, sky;
@@ -523,8 +641,11 @@ struct RenderArgs {
 // ---------------------------------------------------------------------------
 // render_kernel
 // ---------------------------------------------------------------------------
-template <bool STATS, bool SUMSQ, bool FLAT>
-__global__ void __launch_bounds__(64, RT_RENDER_WAVES_PER_SIMD) render_kernel(DevScene S, DevCamera cam, RenderArgs A, float* __restrict__ out_sum,
+// GENERAL = false is the build for scenes made of Lambertian and DiffuseLight
+// surfaces with constant textures and no media (the Cornell box); true adds
+// Metal, Dielectric, Isotropic, checker/noise textures and ConstantMedium.
+template <bool STATS, bool SUMSQ, bool FLAT, bool GENERAL>
+__global__ void __launch_bounds__(64, GENERAL ? 4 : RT_RENDER_WAVES_PER_SIMD) render_kernel(DevScene S, DevCamera cam, RenderArgs A, float* __restrict__ out_sum,
                                                      float* __restrict__ out_sumsq, unsigned long long* __restrict__ stats) {
   // One single-wave workgroup per work item, so a finished wave frees its slot at
   // once instead of waiting for the slowest wave of a larger group.
@@ -634,7 +755,8 @@ __global__ void __launch_bounds__(64, RT_RENDER_WAVES_PER_SIMD) render_kernel(De
 
     // ---- world.hit(r, 0.001, INFINITY), main.rs:166 ----
     if (STATS) cnt.rays += alive;
-    const Hit h = trace_scan<STATS, FLAT>(S, alive, ray, A.t_min, INFINITY, cnt);
+    const PathRng rng = {pixel_id, sample, (unsigned)depth, A.key0, A.key1};
+    const Hit h = trace_scan<STATS, FLAT, GENERAL>(S, alive, ray, A.t_min, INFINITY, rng, cnt);
 
     // ---- color(), main.rs:165-209, one vertex; every lane runs it, dead lanes and
     // misses on primitive 0 with their results masked ----
@@ -642,8 +764,12 @@ __global__ void __launch_bounds__(64, RT_RENDER_WAVES_PER_SIMD) render_kernel(De
     const DevPrim q = S.dprims[hit ? h.prim : 0];
     const Surface sf = finalize_hit(q, ray, h.t);
     const int mat_type = (q.flags >> DP_MAT_SHIFT) & 7;
-    const F3 color = f3(q.color[0], q.color[1], q.color[2]);
+    F3 color = f3(q.color[0], q.color[1], q.color[2]);
     if (STATS) cnt.hits += hit;
+    if (GENERAL && S.textured) {
+      // Texture::value for the lanes whose material has a checker or noise texture.
+      if (hit && (q.flags & DP_TEXTURED)) color = texture_value(S, S.materials[q.flags >> DP_INDEX_SHIFT].texture, sf.p);
+    }
 
     // material.rs:197-203: a light emits towards the side its normal points to and never scatters.
     const bool is_light = mat_type == RT_MAT_DIFFUSE_LIGHT;
@@ -659,7 +785,7 @@ __global__ void __launch_bounds__(64, RT_RENDER_WAVES_PER_SIMD) render_kernel(De
     const F3 radiance = f3(thr.x * le.x, thr.y * le.y, thr.z * le.z);  // what this vertex adds to the sample, before de_nan
 
     // Lambertian under MixturePDF(HitablePDF(light), CosinePDF(normal)), main.rs:173-197.
-    const bool scatters = hit & !is_light & (depth < A.max_depth);
+    const bool scatters = hit & (mat_type == RT_MAT_LAMBERTIAN) & (depth < A.max_depth);
     if (STATS) cnt.shade_events += scatters;
     const float xi1 = u01(w.z), xi2 = u01(w.w);
     // onb.rs:10-21
@@ -678,7 +804,7 @@ __global__ void __launch_bounds__(64, RT_RENDER_WAVES_PER_SIMD) render_kernel(De
     const float cx = __builtin_amdgcn_cosf(xi1) * r2s;
     const float cy = __builtin_amdgcn_sinf(xi1) * r2s;
     const F3 dir_cos = f3(fmaf(cz, ww.x, fmaf(cy, vv.x, cx * uu.x)), fmaf(cz, ww.y, fmaf(cy, vv.y, cx * uu.y)), fmaf(cz, ww.z, fmaf(cy, vv.z, cx * uu.z)));
-    const F3 dir = sel3(pick_light, dir_light, dir_cos);
+    F3 dir = sel3(pick_light, dir_light, dir_cos);
     const float dlen2 = dot3(dir, dir);
     const float inv_len = fast_rsq(dlen2);
     // pdf.rs:19-26
@@ -698,10 +824,67 @@ __global__ void __launch_bounds__(64, RT_RENDER_WAVES_PER_SIMD) render_kernel(De
     // material.rs:76-82
     const float cos_n = fmaxf(dot3(sf.normal, dir) * inv_len, 0.0f);
     const float f = (cos_n * RT_INV_PI_F) * fast_rcp(pdf_val);
-    const F3 thr_next = f3(thr.x * color.x * f, thr.y * color.y * f, thr.z * color.z * f);
+    F3 thr_next = f3(thr.x * color.x * f, thr.y * color.y * f, thr.z * color.z * f);
+    bool scattered = scatters;
+    if (GENERAL && (S.mat_mask & ((1 << RT_MAT_METAL) | (1 << RT_MAT_DIELECTRIC) | (1 << RT_MAT_ISOTROPIC)))) {
+      // Materials of the reference's older scatter() -> (attenuation, ray) form
+      // (material.rs:100-112, 125-159, 217-221, commented out there): the path goes on
+      // along the returned ray weighted by the attenuation, with no pdf involved.
+      const bool deep = depth < A.max_depth;
+      const bool is_metal = hit & deep & (mat_type == RT_MAT_METAL);
+      const bool is_diel = hit & deep & (mat_type == RT_MAT_DIELECTRIC);
+      const bool is_iso = hit & deep & (mat_type == RT_MAT_ISOTROPIC);
+      if (__ballot(is_metal | is_diel | is_iso) != 0ull) {
+        // random_in_unit_sphere (main.rs:211-221): attempt a draws counter (pixel, sample, depth, 256+a)
+        F3 rs = f3(0, 0, 0);
+        bool looking = is_metal | is_iso;
+        unsigned attempt = 0;
+        while (__ballot(looking) != 0ull) {
+          const U4 sw = philox4x32_10(pixel_id, sample, (unsigned)depth, 256u + attempt, A.key0, A.key1);
+          const F3 c = f3(2.0f * u01(sw.x) - 1.0f, 2.0f * u01(sw.y) - 1.0f, 2.0f * u01(sw.z) - 1.0f);
+          const bool ok = looking & (dot3(c, c) < 1.0f);
+          rs = sel3(ok, c, rs);
+          looking &= !ok;
+          ++attempt;
+        }
+        const F3 n = sf.normal;
+        // Metal::scatter
+        const F3 refl_unit = reflect3(unit3(ray.d), n);
+        const F3 m_dir = f3(refl_unit.x + q.fuzz * rs.x, refl_unit.y + q.fuzz * rs.y, refl_unit.z + q.fuzz * rs.z);
+        const bool m_ok = dot3(m_dir, n) > 0.0f;
+        // Dielectric::scatter (reflects the un-normalised incoming direction, material.rs:126)
+        const F3 reflected = reflect3(ray.d, n);
+        const float dn = dot3(ray.d, n);
+        const float d_len = fast_sqrt(dot3(ray.d, ray.d));
+        const bool outside = !(dn > 0.0f);
+        const F3 on_ = outside ? n : f3(-n.x, -n.y, -n.z);
+        const float ni_over_nt = outside ? fast_rcp(q.ref_idx) : q.ref_idx;
+        const float cosine = outside ? -dn * fast_rcp(d_len) : q.ref_idx * dn * fast_rcp(d_len);
+        const F3 uvd = unit3(ray.d);
+        const float dt = dot3(uvd, on_);
+        const float disc = 1.0f - ni_over_nt * ni_over_nt * (1.0f - dt * dt);
+        const float sq = fast_sqrt(disc);
+        const F3 refracted = f3(ni_over_nt * (uvd.x - on_.x * dt) - on_.x * sq, ni_over_nt * (uvd.y - on_.y * dt) - on_.y * sq,
+                                ni_over_nt * (uvd.z - on_.z * dt) - on_.z * sq);
+        float r0 = (1.0f - q.ref_idx) * fast_rcp(1.0f + q.ref_idx);
+        r0 = r0 * r0;
+        const float om = 1.0f - cosine;
+        const float reflect_prob = disc > 0.0f ? r0 + (1.0f - r0) * (om * om) * (om * om) * om : 1.0f;
+        const float xi = u01(w.y << 1);
+        const F3 d_dir = xi < reflect_prob ? reflected : refracted;
+        // Isotropic::scatter
+        const F3 s_dir = is_metal ? m_dir : (is_diel ? d_dir : rs);
+        const F3 atten = is_diel ? f3(1.0f, 1.0f, 1.0f) : color;
+        const bool s_any = is_metal | is_diel | is_iso;
+        const bool s_ok = (is_metal & m_ok) | is_diel | is_iso;
+        dir = sel3(s_any, s_dir, dir);
+        thr_next = sel3(s_any, f3(thr.x * atten.x, thr.y * atten.y, thr.z * atten.z), thr_next);
+        scattered = s_any ? s_ok : scattered;
+      }
+    }
     // A zero or NaN weight fixes the sample's value (0 after de_nan) whatever the
     // rest of the path does, so the path ends there.
-    const bool go_on = scatters & ((thr_next.x > 0.0f) | (thr_next.y > 0.0f) | (thr_next.z > 0.0f));
+    const bool go_on = scattered & ((thr_next.x > 0.0f) | (thr_next.y > 0.0f) | (thr_next.z > 0.0f));
     const bool done = alive & !go_on;
     if (done) {
       // de_nan (main.rs:252-264) then col += (main.rs:108)
@@ -791,6 +974,7 @@ __global__ void tonemap_kernel(const float* __restrict__ sum, size_t n, float sp
 struct rt_ctx {
   int device;
   bool has_scene;
+  bool general;  // the scene needs the GENERAL build of the render kernel
   DevScene dev;
   void* d_scan;
   void* d_prims;
@@ -838,13 +1022,25 @@ int validate_scene(const rt_scene* s) {
   if (s->n_lights == 1 && s->lights[0].type != RT_LIGHT_XZ_RECT) return rt::set_error(RT_ERR_UNSUPPORTED, "light type must be RT_LIGHT_XZ_RECT");
   for (int i = 0; i < s->n_textures; ++i) {
     const rt_texture& t = s->textures[i];
-    if (t.type != RT_TEX_CONSTANT) return rt::set_error(RT_ERR_UNSUPPORTED, "this build renders constant textures only");
+    if (t.type == RT_TEX_CHECKER) {
+      // children are created before their parent (texture.rs:40-45 takes them by value), which also rules out cycles
+      if (t.odd < 0 || t.odd >= i || t.even < 0 || t.even >= i) return rt::set_error(RT_ERR_INVALID, "checker texture children must be earlier textures");
+    } else if (t.type == RT_TEX_NOISE) {
+      if (t.perlin < 0 || t.perlin >= s->n_perlins) return rt::set_error(RT_ERR_INVALID, "noise texture perlin index out of range");
+    } else if (t.type != RT_TEX_CONSTANT) {
+      return rt::set_error(RT_ERR_INVALID, "unknown texture type");
+    }
   }
+  for (int i = 0; i < s->n_perlins; ++i)
+    for (int k = 0; k < 256; ++k) {
+      const rt_perlin& pn = s->perlins[i];
+      if ((pn.perm_x[k] | pn.perm_y[k] | pn.perm_z[k]) & ~255) return rt::set_error(RT_ERR_INVALID, "perlin permutation entry outside 0..255");
+    }
   for (int i = 0; i < s->n_materials; ++i) {
     const rt_material& m = s->materials[i];
-    if (m.type != RT_MAT_LAMBERTIAN && m.type != RT_MAT_DIFFUSE_LIGHT)
-      return rt::set_error(RT_ERR_UNSUPPORTED, "this build renders Lambertian and DiffuseLight materials only");
-    if (m.texture < 0 || m.texture >= s->n_textures) return rt::set_error(RT_ERR_INVALID, "material texture index out of range");
+    if (m.type < RT_MAT_LAMBERTIAN || m.type > RT_MAT_ISOTROPIC) return rt::set_error(RT_ERR_INVALID, "unknown material type");
+    const bool textured = m.type == RT_MAT_LAMBERTIAN || m.type == RT_MAT_DIFFUSE_LIGHT || m.type == RT_MAT_ISOTROPIC;
+    if (textured && (m.texture < 0 || m.texture >= s->n_textures)) return rt::set_error(RT_ERR_INVALID, "material texture index out of range");
   }
   for (int i = 0; i < s->n_prims; ++i) {
     const rt_prim& p = s->prims[i];
@@ -855,9 +1051,13 @@ int validate_scene(const rt_scene* s) {
   }
   for (int i = 0; i < s->n_objects; ++i) {
     const rt_object& o = s->objects[i];
-    if (o.kind == RT_OBJ_MEDIUM) return rt::set_error(RT_ERR_UNSUPPORTED, "this build does not render ConstantMedium objects");
-    if (o.kind == RT_OBJ_LIST) {
+    if (o.kind == RT_OBJ_LIST || o.kind == RT_OBJ_MEDIUM) {
       if (o.first < 0 || o.count <= 0 || o.first + o.count > s->n_prims) return rt::set_error(RT_ERR_INVALID, "object primitive range out of bounds");
+      if (o.kind == RT_OBJ_MEDIUM) {
+        if (o.material < 0 || o.material >= s->n_materials) return rt::set_error(RT_ERR_INVALID, "medium material index out of range");
+        if (o.medium_index < 0 || o.medium_index >= s->n_objects) return rt::set_error(RT_ERR_INVALID, "medium ordinal out of range");
+        if (!(o.density > 0.0f)) return rt::set_error(RT_ERR_INVALID, "medium density must be positive");
+      }
     } else if (o.kind == RT_OBJ_BVH) {
       if (o.first <= 0 || o.first >= s->n_nodes) return rt::set_error(RT_ERR_INVALID, "object sub-tree root out of range");
     } else {
@@ -899,6 +1099,7 @@ struct ScanBuilder {
   std::vector<int> leaves;
   std::vector<ScanNode> out;
   std::vector<int> prim_obj;
+  std::vector<int> media;  // object index of each ConstantMedium, in scan order
   bool any_interior;
 };
 
@@ -991,14 +1192,24 @@ int build_scan(ScanBuilder* B, int idx, bool in_sub, bool collapsed, bool tree_r
   sn.f[0] = ob.sin_theta; sn.f[1] = ob.cos_theta;
   sn.f[2] = ob.offset[0]; sn.f[3] = ob.offset[1]; sn.f[4] = ob.offset[2];
   const size_t at = B->out.size();
-  if (ob.kind == RT_OBJ_LIST) {
+  if (ob.kind == RT_OBJ_LIST || ob.kind == RT_OBJ_MEDIUM) {
+    const bool medium = ob.kind == RT_OBJ_MEDIUM;
     for (int k = ob.first; k < ob.first + ob.count; ++k) B->prim_obj[k] = ref;
-    sn.kind = K_OBJ_LIST;
+    sn.kind = medium ? K_MEDIUM : K_OBJ_LIST;
     sn.a = ob.first;
     sn.b = ob.count | box6_flag(s, ob.first, ob.count) | (ob.xform << 24);
-    sn.skip = (int)at + ((sn.b & LIST_IS_BOX6) ? 3 : 1);
+    sn.skip = (int)at + ((sn.b & LIST_IS_BOX6) ? 3 : 1) + (medium ? 1 : 0);
     B->out.push_back(sn);
     if (sn.b & LIST_IS_BOX6) push_box6(s, ob.first, &B->out);
+    if (medium) {
+      ScanNode ext;
+      std::memset(&ext, 0, sizeof(ext));
+      ext.f[0] = ob.density;
+      ext.a = ob.medium_index;
+      ext.b = s->n_prims + (int)B->media.size();  // its DevPrim
+      B->out.push_back(ext);
+      B->media.push_back(ref);
+    }
     return RT_OK;
   }
   // RT_OBJ_BVH: the sub-tree follows inline, in the object's frame.
@@ -1092,10 +1303,10 @@ int launch_render(rt_ctx* ctx, const rt_camera* cam, const rt_render_params* p, 
   const int n_items = n_tiles * A.n_chunks;
   const dim3 grid(n_items), block(64);
   typedef void (*RenderFn)(DevScene, DevCamera, RenderArgs, float*, float*, unsigned long long*);
-  static const RenderFn table[8] = {
-      render_kernel<false, false, false>, render_kernel<false, false, true>, render_kernel<false, true, false>, render_kernel<false, true, true>,
-      render_kernel<true, false, false>,  render_kernel<true, false, true>,  render_kernel<true, true, false>,  render_kernel<true, true, true>};
-  const RenderFn fn = table[(stats ? 4 : 0) | (d_sumsq ? 2 : 0) | (ctx->dev.flat ? 1 : 0)];
+#define RT_ROW(ST, SQ) render_kernel<ST, SQ, false, false>, render_kernel<ST, SQ, false, true>, render_kernel<ST, SQ, true, false>, render_kernel<ST, SQ, true, true>
+  static const RenderFn table[16] = {RT_ROW(false, false), RT_ROW(false, true), RT_ROW(true, false), RT_ROW(true, true)};
+#undef RT_ROW
+  const RenderFn fn = table[(stats ? 8 : 0) | (d_sumsq ? 4 : 0) | (ctx->dev.flat ? 2 : 0) | (ctx->general ? 1 : 0)];
   hipLaunchKernelGGL(fn, grid, block, 0, stream, ctx->dev, dc, A, k_sum, k_sumsq, ctx->d_stats);
   HIP_TRY(hipGetLastError());
   if (A.n_chunks > 1) {
@@ -1165,21 +1376,31 @@ int rt_upload_scene(rt_ctx* ctx, const rt_scene* s) {
   if ((rc = upload(&ctx->d_scan, scan.data(), scan.size())) != RT_OK) return rc;
   if ((rc = upload(&ctx->d_prims, s->prims, (size_t)s->n_prims)) != RT_OK) return rc;
   // One DevPrim per primitive: geometry + the frame it lives in + its material.
-  std::vector<DevPrim> dprims((size_t)s->n_prims);
-  for (int i = 0; i < s->n_prims; ++i) {
-    const rt_prim& q = s->prims[i];
+  std::vector<DevPrim> dprims((size_t)s->n_prims + B.media.size());
+  int mat_mask = 0, textured = 0;
+  for (size_t i = 0; i < dprims.size(); ++i) {
+    const bool is_medium = i >= (size_t)s->n_prims;
+    rt_prim q;
+    std::memset(&q, 0, sizeof(q));
+    if (is_medium) {
+      q.type = DP_TYPE_MEDIUM;
+      q.material = s->objects[B.media[i - (size_t)s->n_prims]].material;
+    } else {
+      q = s->prims[i];
+    }
     const rt_material& m = s->materials[q.material];
-    DevPrim& d = dprims[(size_t)i];
+    mat_mask |= 1 << m.type;
+    DevPrim& d = dprims[i];
     std::memset(&d, 0, sizeof(d));
     d.cos_t = 1.0f;
     int xform = 0;
-    if (B.prim_obj[(size_t)i] >= 0) {
-      const rt_object& ob = s->objects[B.prim_obj[(size_t)i]];
+    if (!is_medium && B.prim_obj[i] >= 0) {
+      const rt_object& ob = s->objects[B.prim_obj[i]];
       xform = ob.xform & 3;
       d.sin_t = ob.sin_theta; d.cos_t = ob.cos_theta;
       d.off[0] = ob.offset[0]; d.off[1] = ob.offset[1]; d.off[2] = ob.offset[2];
     }
-    d.flags = (q.type & RT_PRIM_TYPE_MASK) | ((q.type & RT_PRIM_FLIP) ? DP_FLIP : 0) | (xform << DP_XFORM_SHIFT) |
+    d.flags = (q.type & DP_TYPE_MASK) | ((q.type & RT_PRIM_FLIP) ? DP_FLIP : 0) | (xform << DP_XFORM_SHIFT) |
               (m.type << DP_MAT_SHIFT) | (q.material << DP_INDEX_SHIFT);
     for (int k = 0; k < 5; ++k) d.f[k] = q.f[k];
     if (m.type == RT_MAT_METAL) {
@@ -1187,7 +1408,7 @@ int rt_upload_scene(rt_ctx* ctx, const rt_scene* s) {
     } else if (m.texture >= 0 && m.texture < s->n_textures) {
       const rt_texture& t = s->textures[m.texture];
       if (t.type == RT_TEX_CONSTANT) for (int k = 0; k < 3; ++k) d.color[k] = t.color[k];
-      else d.flags |= DP_TEXTURED;
+      else { d.flags |= DP_TEXTURED; textured = 1; }
     }
     d.fuzz = m.fuzz;
     d.ref_idx = m.ref_idx;
@@ -1202,6 +1423,8 @@ int rt_upload_scene(rt_ctx* ctx, const rt_scene* s) {
   d.prims = (const rt_prim*)ctx->d_prims;
   d.dprims = (const DevPrim*)ctx->d_dprims;
   d.flat = B.any_interior ? 0 : 1;
+  d.mat_mask = mat_mask;
+  d.textured = textured;
   d.materials = (const rt_material*)ctx->d_materials;
   d.textures = (const rt_texture*)ctx->d_textures;
   d.perlins = (const rt_perlin*)ctx->d_perlins;
@@ -1209,6 +1432,7 @@ int rt_upload_scene(rt_ctx* ctx, const rt_scene* s) {
   d.n_prims = s->n_prims;
   d.n_lights = s->n_lights;
   if (s->n_lights > 0) d.light = s->lights[0];
+  ctx->general = textured || !B.media.empty() || (mat_mask & ~((1 << RT_MAT_LAMBERTIAN) | (1 << RT_MAT_DIFFUSE_LIGHT))) != 0;
   ctx->has_scene = true;
   return RT_OK;
 }
