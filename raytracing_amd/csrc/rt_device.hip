@@ -105,8 +105,28 @@ struct DevScene {
   int mat_mask;  // bit RT_MAT_* set when a primitive or medium uses that material
   int textured;  // some material needs Texture::value (checker / noise)
   int flat;  // 1: the scan array holds leaves only (every skip is the next index)
+  // Stack traversal (scenes with more than a handful of leaves): the breadth-first
+  // nodes with packed leaf information, and the objects their leaves refer to.  In
+  // that mode `scan` holds only the ConstantMedium nodes, walked after the tree.
+  const struct BNode* bnodes;
+  const rt_object* objects;
+  int stack_mode;
   rt_light light;
 };
+
+// Breadth-first node for the per-lane stack traversal, 32 bytes (two 16-byte loads).
+//   interior: left  = left child  | split axis << 29
+//             right = right child | (left child is the far one for a positive direction) << 29
+//   leaf:     left  = ~ref (negative); right = count | depth-first leaf rank << 8, count 0 = objects[ref]
+struct BNode {
+  float bmin[3];
+  int left;
+  float bmax[3];
+  int right;
+};
+#define BN_INDEX_MASK 0x1fffffff
+#define STACK_DEPTH 32
+#define STACK_RESTORE 0xffffffffu
 
 struct DevCamera {
   float origin[3], llc[3], horizontal[3], vertical[3], u[3], v[3];
@@ -460,16 +480,125 @@ __device__ __forceinline__ void scan_range(const DevScene& S, int begin, int end
   }
 }
 
+// Per-lane nearest hit over the breadth-first tree with a stack in LDS (one
+// column per lane).  Used for scenes too large for the wave-uniform scan: every
+// lane follows its own ray, nearer child first, pruning boxes entered beyond its
+// best hit.  The reference visits both children and lets the right one win an
+// exact tie (bvh.rs:204-217); visiting in another order gives the same winner
+// when a tie goes to the leaf that comes later in depth-first order, so each leaf
+// carries that rank.  A leaf that is a Translate/RotateY over a BvhNode pushes a
+// marker, switches the lane to the object's frame and descends; the marker
+// switches it back.
+template <bool STATS>
+__device__ __forceinline__ void prim_list_lane(const DevScene& S, int first, int count, int rank, const RayF& r, float t_min, float t_max,
+                                               Hit& best, int& best_rank, Counters& cnt) {
+  float loc_t = t_max;
+  int loc_prim = -1;
+  for (int qi = first; qi < first + count; ++qi) {
+    const rt_prim q = S.prims[qi];
+    const int type = q.type & RT_PRIM_TYPE_MASK;
+    float t = 0.0f;
+    bool h;
+    if (type == RT_PRIM_SPHERE) {
+      h = sphere_test(q.f, r, t_min, loc_t, t);
+      if (STATS) cnt.sphere_tests++;
+    } else {
+      if (type == RT_PRIM_XY_RECT) h = rect_test<2, 0, 1>(q.f, r, t_min, loc_t, t);
+      else if (type == RT_PRIM_XZ_RECT) h = rect_test<1, 0, 2>(q.f, r, t_min, loc_t, t);
+      else h = rect_test<0, 1, 2>(q.f, r, t_min, loc_t, t);
+      if (STATS) cnt.rect_tests++;
+    }
+    if (h) {
+      loc_t = t;
+      loc_prim = qi;
+    }
+  }
+  if (loc_prim >= 0 && (loc_t < best.t || (!(best.t < loc_t) && rank > best_rank))) {
+    best.t = loc_t;
+    best.prim = loc_prim;
+    best_rank = rank;
+  }
+}
+
+template <bool STATS>
+__device__ __forceinline__ void trace_stack(const DevScene& S, unsigned* __restrict__ stk, const RayF& w, float t_min, float t_max, Hit& best,
+                                            Counters& cnt) {
+  // stk points at this lane's column; consecutive entries are 64 dwords apart.
+  int best_rank = -1;
+  RayF r = w;
+  Signs sg = ray_signs(r);
+  int sp = 0;
+  int node = 0;
+  for (;;) {
+    if (node < 0) {
+      if (sp == 0) break;
+      --sp;
+      const unsigned x = stk[sp * 64];
+      if (x == STACK_RESTORE) {
+        r = w;
+        sg = ray_signs(r);
+        continue;
+      }
+      node = (int)x;
+    }
+    const float4 lo = *(const float4*)&S.bnodes[node];
+    const float4 hi = *((const float4*)&S.bnodes[node] + 1);
+    ScanNode n;  // only the box fields are used by slab_test
+    n.bmin[0] = lo.x; n.bmin[1] = lo.y; n.bmin[2] = lo.z;
+    n.bmax[0] = hi.x; n.bmax[1] = hi.y; n.bmax[2] = hi.z;
+    const int left = __float_as_int(lo.w), right = __float_as_int(hi.w);
+    if (STATS) cnt.node_tests++;
+    node = -1;
+    if (!slab_test(n, r, sg, t_min, t_max, best.t)) continue;
+    if (left >= 0) {
+      const int axis = left >> 29;
+      const bool neg = axis == 0 ? sg.x : (axis == 1 ? sg.y : sg.z);
+      const bool left_far = (((right >> 29) & 1) != 0) != neg;
+      const int l = left & BN_INDEX_MASK, rr = right & BN_INDEX_MASK;
+      stk[sp * 64] = (unsigned)(left_far ? l : rr);
+      ++sp;
+      node = left_far ? rr : l;
+      continue;
+    }
+    const int ref = ~left;
+    const int count = right & 0xff, rank = right >> 8;
+    if (count > 0) {
+      prim_list_lane<STATS>(S, ref, count, rank, r, t_min, t_max, best, best_rank, cnt);
+      continue;
+    }
+    const rt_object ob = S.objects[ref];
+    if (ob.kind == RT_OBJ_MEDIUM) continue;  // walked separately: it needs random numbers
+    const RayF q = to_object_frame<true>(w, ob.xform, ob.sin_theta, ob.cos_theta, ob.offset[0], ob.offset[1], ob.offset[2]);
+    if (STATS) cnt.instance_ops++;
+    if (ob.kind == RT_OBJ_LIST) {
+      prim_list_lane<STATS>(S, ob.first, ob.count, rank, q, t_min, t_max, best, best_rank, cnt);
+    } else {
+      stk[sp * 64] = STACK_RESTORE;
+      ++sp;
+      r = q;
+      sg = ray_signs(r);
+      node = ob.first;
+    }
+  }
+}
+
 // Nearest hit of BvhNode::hit (bvh.rs:197-228).  Must be called by all 64 lanes.
-// FLAT is chosen by the host per scene (DevScene::flat): each variant is its own
-// kernel so the register allocator only sees the code that scene can reach.
-template <bool STATS, bool FLAT, bool MEDIA>
-__device__ __forceinline__ Hit trace_scan(const DevScene& S, bool active, const RayF& w, float t_min, float t_max, const PathRng& rng,
-                                          Counters& cnt) {
+// TRAV is chosen by the host per scene: each variant is its own kernel so the
+// register allocator only sees the code that scene can reach.
+enum { TRAV_SCAN = 0, TRAV_FLAT = 1, TRAV_STACK = 2 };
+template <bool STATS, int TRAV, bool MEDIA>
+__device__ __forceinline__ Hit trace_scan(const DevScene& S, unsigned* stk, bool active, const RayF& w, float t_min, float t_max,
+                                          const PathRng& rng, Counters& cnt) {
   Hit best;
   best.t = t_max;
   best.prim = -1;
-  scan_range<STATS, FLAT, MEDIA, 0>(S, 0, S.n_scan, active, w, t_min, t_max, rng, best, cnt);
+  if (TRAV == TRAV_STACK) {
+    if (active) trace_stack<STATS>(S, stk, w, t_min, t_max, best, cnt);
+    // what is left in the scan array in this mode: the ConstantMedium nodes
+    if (MEDIA && S.n_scan > 0) scan_range<STATS, true, true, 0>(S, 0, S.n_scan, active, w, t_min, t_max, rng, best, cnt);
+  } else {
+    scan_range<STATS, TRAV == TRAV_FLAT, MEDIA, 0>(S, 0, S.n_scan, active, w, t_min, t_max, rng, best, cnt);
+  }
   return best;
 }
 
@@ -506,10 +635,12 @@ __device__ __forceinline__ Surface finalize_hit(const DevPrim& q, const RayF& w,
 // ---------------------------------------------------------------------------
 // trace_kernel
 // ---------------------------------------------------------------------------
-template <bool FLAT>
+template <int TRAV>
 __global__ void __launch_bounds__(256) trace_kernel(DevScene S, const float* __restrict__ o, const float* __restrict__ d, size_t n,
                                                     float t_min, float t_max, int* __restrict__ prim_id, float* __restrict__ t_out,
                                                     float* __restrict__ normal, float* __restrict__ p_out) {
+  __shared__ unsigned stack_lds[TRAV == TRAV_STACK ? 4 * STACK_DEPTH * 64 : 64];
+  unsigned* stk = stack_lds + (TRAV == TRAV_STACK ? (threadIdx.x >> 6) * STACK_DEPTH * 64 : 0) + (threadIdx.x & 63);
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   // Whole waves stay in the loop together: the traversal uses wave-wide operations.
   const size_t n_round = (n + 63) / 64 * 64;
@@ -519,7 +650,7 @@ __global__ void __launch_bounds__(256) trace_kernel(DevScene S, const float* __r
     const RayF w = make_ray(f3(o[3 * at], o[3 * at + 1], o[3 * at + 2]), f3(d[3 * at], d[3 * at + 1], d[3 * at + 2]));
     Counters cnt;
     PathRng rng = {0u, 0u, 0u, 0u, 0u};  // a deterministic query takes no random numbers: media are skipped
-    const Hit h = trace_scan<false, FLAT, false>(S, active, w, t_min, t_max, rng, cnt);
+    const Hit h = trace_scan<false, TRAV, false>(S, stk, active, w, t_min, t_max, rng, cnt);
     if (active) {
       prim_id[idx] = h.prim;
       t_out[idx] = h.prim >= 0 ? h.t : 0.0f;
@@ -644,12 +775,14 @@ struct RenderArgs {
 // GENERAL = false is the build for scenes made of Lambertian and DiffuseLight
 // surfaces with constant textures and no media (the Cornell box); true adds
 // Metal, Dielectric, Isotropic, checker/noise textures and ConstantMedium.
-template <bool STATS, bool SUMSQ, bool FLAT, bool GENERAL>
-__global__ void __launch_bounds__(64, GENERAL ? 4 : RT_RENDER_WAVES_PER_SIMD) render_kernel(DevScene S, DevCamera cam, RenderArgs A, float* __restrict__ out_sum,
+template <bool STATS, bool SUMSQ, int TRAV, bool GENERAL>
+__global__ void __launch_bounds__(64, (GENERAL || TRAV == TRAV_STACK) ? 4 : RT_RENDER_WAVES_PER_SIMD) render_kernel(DevScene S, DevCamera cam, RenderArgs A, float* __restrict__ out_sum,
                                                      float* __restrict__ out_sumsq, unsigned long long* __restrict__ stats) {
   // One single-wave workgroup per work item, so a finished wave frees its slot at
   // once instead of waiting for the slowest wave of a larger group.
   __shared__ float acc[1][6][64];
+  __shared__ unsigned stack_lds[TRAV == TRAV_STACK ? STACK_DEPTH * 64 : 64];
+  unsigned* stk = stack_lds + (threadIdx.x & 63);
   const int lane = threadIdx.x & 63;
   const int wib = 0;
   // One wave = one work item = (tile, sample chunk).  With more than one chunk
@@ -756,7 +889,7 @@ __global__ void __launch_bounds__(64, GENERAL ? 4 : RT_RENDER_WAVES_PER_SIMD) re
     // ---- world.hit(r, 0.001, INFINITY), main.rs:166 ----
     if (STATS) cnt.rays += alive;
     const PathRng rng = {pixel_id, sample, (unsigned)depth, A.key0, A.key1};
-    const Hit h = trace_scan<STATS, FLAT, GENERAL>(S, alive, ray, A.t_min, INFINITY, rng, cnt);
+    const Hit h = trace_scan<STATS, TRAV, GENERAL>(S, stk, alive, ray, A.t_min, INFINITY, rng, cnt);
 
     // ---- color(), main.rs:165-209, one vertex; every lane runs it, dead lanes and
     // misses on primitive 0 with their results masked ----
@@ -979,6 +1112,8 @@ struct rt_ctx {
   void* d_scan;
   void* d_prims;
   void* d_dprims;
+  void* d_bnodes;
+  void* d_objects;
   void* d_materials;
   void* d_textures;
   void* d_perlins;
@@ -1001,7 +1136,7 @@ int hip_fail(hipError_t e, const char* what) {
   } while (0)
 
 void free_scene(rt_ctx* ctx) {
-  void** ptrs[] = {&ctx->d_scan, &ctx->d_prims, &ctx->d_dprims, &ctx->d_materials, &ctx->d_textures, &ctx->d_perlins};
+  void** ptrs[] = {&ctx->d_scan, &ctx->d_prims, &ctx->d_dprims, &ctx->d_bnodes, &ctx->d_objects, &ctx->d_materials, &ctx->d_textures, &ctx->d_perlins};
   for (size_t i = 0; i < sizeof(ptrs) / sizeof(ptrs[0]); ++i) {
     if (*ptrs[i]) (void)hipFree(*ptrs[i]);
     *ptrs[i] = nullptr;
@@ -1229,6 +1364,50 @@ int build_scan(ScanBuilder* B, int idx, bool in_sub, bool collapsed, bool tree_r
   return RT_OK;
 }
 
+// Depth (in nodes) of the tree under idx, following object sub-trees, for sizing the traversal stack.
+int tree_depth(const rt_scene* s, int idx) {
+  const rt_node& n = s->nodes[idx];
+  if (n.left >= 0) {
+    const int a = tree_depth(s, n.left), b = tree_depth(s, n.right);
+    return 1 + (a > b ? a : b);
+  }
+  if (n.right == 0 && s->objects[~n.left].kind == RT_OBJ_BVH) return 2 + tree_depth(s, s->objects[~n.left].first);
+  return 1;
+}
+
+// Fills the stack-traversal copy of the nodes under idx: split axis and child
+// order for interior nodes, primitive count and depth-first rank for leaves.
+int build_bnodes(const rt_scene* s, int idx, std::vector<BNode>* out, int* rank) {
+  const rt_node& n = s->nodes[idx];
+  BNode& b = (*out)[(size_t)idx];
+  for (int c = 0; c < 3; ++c) { b.bmin[c] = n.bmin[c]; b.bmax[c] = n.bmax[c]; }
+  if (n.left >= 0) {
+    if (n.left > BN_INDEX_MASK || n.right > BN_INDEX_MASK) return rt::set_error(RT_ERR_UNSUPPORTED, "too many nodes");
+    const rt_node& l = s->nodes[n.left];
+    const rt_node& r = s->nodes[n.right];
+    int axis = 0;
+    float best = -1.0f;
+    for (int c = 0; c < 3; ++c) {
+      const float d = std::fabs((l.bmin[c] + l.bmax[c]) - (r.bmin[c] + r.bmax[c]));
+      if (d > best) { best = d; axis = c; }
+    }
+    // for a ray travelling in +axis the child with the larger centre is the far one
+    const bool left_far_pos = (l.bmin[axis] + l.bmax[axis]) > (r.bmin[axis] + r.bmax[axis]);
+    b.left = n.left | (axis << 29);
+    b.right = n.right | ((left_far_pos ? 1 : 0) << 29);
+    int rc = build_bnodes(s, n.left, out, rank);
+    if (rc != RT_OK) return rc;
+    return build_bnodes(s, n.right, out, rank);
+  }
+  if (n.right > 255) return rt::set_error(RT_ERR_UNSUPPORTED, "a leaf list longer than 255 primitives");
+  if (*rank >= (1 << 23)) return rt::set_error(RT_ERR_UNSUPPORTED, "too many leaves");
+  b.left = n.left;
+  b.right = n.right | (*rank << 8);
+  ++*rank;
+  if (n.right == 0 && s->objects[~n.left].kind == RT_OBJ_BVH) return build_bnodes(s, s->objects[~n.left].first, out, rank);
+  return RT_OK;
+}
+
 template <class T> int upload(void** dst, const T* src, size_t n) {
   *dst = nullptr;
   const size_t bytes = (n ? n : 1) * sizeof(T);
@@ -1303,10 +1482,13 @@ int launch_render(rt_ctx* ctx, const rt_camera* cam, const rt_render_params* p, 
   const int n_items = n_tiles * A.n_chunks;
   const dim3 grid(n_items), block(64);
   typedef void (*RenderFn)(DevScene, DevCamera, RenderArgs, float*, float*, unsigned long long*);
-#define RT_ROW(ST, SQ) render_kernel<ST, SQ, false, false>, render_kernel<ST, SQ, false, true>, render_kernel<ST, SQ, true, false>, render_kernel<ST, SQ, true, true>
-  static const RenderFn table[16] = {RT_ROW(false, false), RT_ROW(false, true), RT_ROW(true, false), RT_ROW(true, true)};
+#define RT_ROW(ST, SQ)                                                                                                      \
+  render_kernel<ST, SQ, TRAV_SCAN, false>, render_kernel<ST, SQ, TRAV_SCAN, true>, render_kernel<ST, SQ, TRAV_FLAT, false>, \
+      render_kernel<ST, SQ, TRAV_FLAT, true>, render_kernel<ST, SQ, TRAV_STACK, false>, render_kernel<ST, SQ, TRAV_STACK, true>
+  static const RenderFn table[24] = {RT_ROW(false, false), RT_ROW(false, true), RT_ROW(true, false), RT_ROW(true, true)};
 #undef RT_ROW
-  const RenderFn fn = table[(stats ? 8 : 0) | (d_sumsq ? 4 : 0) | (ctx->dev.flat ? 2 : 0) | (ctx->general ? 1 : 0)];
+  const int trav = ctx->dev.stack_mode ? TRAV_STACK : (ctx->dev.flat ? TRAV_FLAT : TRAV_SCAN);
+  const RenderFn fn = table[(stats ? 12 : 0) + (d_sumsq ? 6 : 0) + trav * 2 + (ctx->general ? 1 : 0)];
   hipLaunchKernelGGL(fn, grid, block, 0, stream, ctx->dev, dc, A, k_sum, k_sumsq, ctx->d_stats);
   HIP_TRY(hipGetLastError());
   if (A.n_chunks > 1) {
@@ -1370,7 +1552,27 @@ int rt_upload_scene(rt_ctx* ctx, const rt_scene* s) {
   if (rc < 0) return rc;
   rc = build_scan(&B, 0, false, false, true, -1);
   if (rc != RT_OK) return rc;
-  const std::vector<ScanNode>& scan = B.out;
+  // More than a treelet's worth of leaves: per-lane stack traversal over the
+  // breadth-first nodes; the scan array then keeps only the ConstantMedium nodes.
+  const bool stack_mode = B.any_interior && tree_depth(s, 0) <= STACK_DEPTH - 2;
+  std::vector<BNode> bnodes;
+  std::vector<ScanNode> media_scan;
+  if (stack_mode) {
+    bnodes.assign((size_t)s->n_nodes, BNode());
+    int rank = 0;
+    rc = build_bnodes(s, 0, &bnodes, &rank);
+    if (rc != RT_OK) return rc;
+    for (size_t i = 0; i < B.out.size();) {
+      const int slots = B.out[i].kind == K_INTERIOR ? 1 : B.out[i].skip - (int)i;
+      if (B.out[i].kind == K_MEDIUM) {
+        const int at = (int)media_scan.size();
+        for (int k = 0; k < slots; ++k) media_scan.push_back(B.out[i + (size_t)k]);
+        media_scan[(size_t)at].skip = at + slots;
+      }
+      i += (B.out[i].kind == K_OBJ_BVH) ? 1 : (size_t)slots;
+    }
+  }
+  const std::vector<ScanNode>& scan = stack_mode ? media_scan : B.out;
   HIP_TRY(hipSetDevice(ctx->device));
   free_scene(ctx);
   if ((rc = upload(&ctx->d_scan, scan.data(), scan.size())) != RT_OK) return rc;
@@ -1414,6 +1616,8 @@ int rt_upload_scene(rt_ctx* ctx, const rt_scene* s) {
     d.ref_idx = m.ref_idx;
   }
   if ((rc = upload(&ctx->d_dprims, dprims.data(), dprims.size())) != RT_OK) return rc;
+  if ((rc = upload(&ctx->d_bnodes, bnodes.data(), bnodes.size())) != RT_OK) return rc;
+  if ((rc = upload(&ctx->d_objects, s->objects, (size_t)s->n_objects)) != RT_OK) return rc;
   if ((rc = upload(&ctx->d_materials, s->materials, (size_t)s->n_materials)) != RT_OK) return rc;
   if ((rc = upload(&ctx->d_textures, s->textures, (size_t)s->n_textures)) != RT_OK) return rc;
   if ((rc = upload(&ctx->d_perlins, s->perlins, (size_t)s->n_perlins)) != RT_OK) return rc;
@@ -1422,7 +1626,10 @@ int rt_upload_scene(rt_ctx* ctx, const rt_scene* s) {
   d.scan = (const ScanNode*)ctx->d_scan;
   d.prims = (const rt_prim*)ctx->d_prims;
   d.dprims = (const DevPrim*)ctx->d_dprims;
-  d.flat = B.any_interior ? 0 : 1;
+  d.flat = (B.any_interior && !stack_mode) ? 0 : 1;
+  d.bnodes = (const BNode*)ctx->d_bnodes;
+  d.objects = (const rt_object*)ctx->d_objects;
+  d.stack_mode = stack_mode ? 1 : 0;
   d.mat_mask = mat_mask;
   d.textured = textured;
   d.materials = (const rt_material*)ctx->d_materials;
@@ -1506,8 +1713,9 @@ int rt_trace_closest(rt_ctx* ctx, const float* o, const float* d, size_t n, floa
   if (e == hipSuccess) {
     size_t blocks = (n + 255) / 256;
     if (blocks > 4096) blocks = 4096;
-    if (ctx->dev.flat) hipLaunchKernelGGL(trace_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, 0, ctx->dev, d_o, d_d, n, t_min, t_max, d_id, d_t, d_n, d_p);
-    else hipLaunchKernelGGL(trace_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, 0, ctx->dev, d_o, d_d, n, t_min, t_max, d_id, d_t, d_n, d_p);
+    if (ctx->dev.stack_mode) hipLaunchKernelGGL(trace_kernel<TRAV_STACK>, dim3((unsigned)blocks), dim3(256), 0, 0, ctx->dev, d_o, d_d, n, t_min, t_max, d_id, d_t, d_n, d_p);
+    else if (ctx->dev.flat) hipLaunchKernelGGL(trace_kernel<TRAV_FLAT>, dim3((unsigned)blocks), dim3(256), 0, 0, ctx->dev, d_o, d_d, n, t_min, t_max, d_id, d_t, d_n, d_p);
+    else hipLaunchKernelGGL(trace_kernel<TRAV_SCAN>, dim3((unsigned)blocks), dim3(256), 0, 0, ctx->dev, d_o, d_d, n, t_min, t_max, d_id, d_t, d_n, d_p);
     e = hipGetLastError();
   }
   if (e == hipSuccess) e = hipDeviceSynchronize();
