@@ -49,7 +49,7 @@ def main():
     ap.add_argument("--nx", type=int, default=1024)
     ap.add_argument("--ny", type=int, default=1024)
     ap.add_argument("--spp", type=int, default=1000)
-    ap.add_argument("--cpu-spp", type=int, default=16, help="samples per pixel of the CPU baseline's bounded run")
+    ap.add_argument("--cpu-spp", type=int, default=256, help="samples per pixel of the CPU baseline's bounded run")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stats", action="store_true")
     args = ap.parse_args()
@@ -83,9 +83,8 @@ def main():
     r.upload_scene(flat)
 
     # sample-range split: rank g renders samples [g*spp/N, (g+1)*spp/N) of every pixel
-    s_begin = spp * rank // world
-    s_end = spp * (rank + 1) // world
-    params = make_params(nx, ny, s_end - s_begin, sample_begin=s_begin, seed=seed)
+    from raytracing_amd.distributed import reduce_to_root, shard_params
+    params = shard_params(make_params(nx, ny, spp, seed=seed), rank, world, "samples")
     buf = torch.empty(ny * nx * 3, dtype=torch.float32, device=dev)
     stream = torch.cuda.current_stream(dev)
 
@@ -95,8 +94,7 @@ def main():
         r.render_device(cam, params, buf.data_ptr(), None, stream.cuda_stream)
         if ev1 is not None:
             ev1.record(stream)
-        if world > 1:
-            dist.reduce(buf, dst=0, op=dist.ReduceOp.SUM)
+        reduce_to_root(buf)
 
     def fence():
         torch.cuda.synchronize(dev)

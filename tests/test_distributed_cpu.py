@@ -1,0 +1,77 @@
+"""The N > 1 path on CPU: two processes, gloo backend, the same shard_params /
+reduce_to_root code bench.py uses on GPUs.  The renderer behind it here is the
+CPU oracle (test infrastructure), because this container has no GPU; what is
+under test is the sharding arithmetic and the collective."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, mode, out_path):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from conftest import CornellFixture
+    from oracle import binding as orc
+    from raytracing_amd import make_params
+    from raytracing_amd.distributed import reduce_to_root, shard_params
+    c = CornellFixture()
+    params = make_params(96, 72, 10, seed=21)
+    mine = shard_params(params, rank, world, mode)
+    s, _ = orc.render(c.flat, c.camera.c, mine, mode=orc.ORC_F32_FUSED, n_threads=2)
+    t = torch.from_numpy(np.ascontiguousarray(s, dtype=np.float32))
+    reduce_to_root(t)
+    if rank == 0:
+        np.save(out_path, t.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["samples", "tiles"])
+def test_two_ranks_reproduce_the_single_rank_image(tmp_path, orc, cornell, mode):
+    from raytracing_amd import make_params
+    out = str(tmp_path / ("sum_%s.npy" % mode))
+    mp.spawn(_worker, args=(2, _free_port(), mode, out), nprocs=2, join=True)
+    got = np.load(out)
+    whole, _ = orc.render(cornell.flat, cornell.camera.c, make_params(96, 72, 10, seed=21), mode=orc.ORC_F32_FUSED, n_threads=4)
+    assert got.shape == (72, 96, 3)
+    assert np.allclose(got, whole.astype(np.float32), rtol=1e-5, atol=1e-5)
+    assert got.sum() > 0
+
+
+def test_shard_params_cover_every_sample_once():
+    from raytracing_amd import make_params
+    from raytracing_amd.distributed import shard_params
+    p = make_params(8, 8, 1000, sample_begin=5)
+    for world in (1, 2, 3, 8):
+        ranges = []
+        for r in range(world):
+            q = shard_params(p, r, world, "samples")
+            ranges.append((q.sample_begin, q.sample_begin + q.spp))
+            assert (q.nx, q.ny, q.seed, q.shard_count) == (p.nx, p.ny, p.seed, 1)
+        assert ranges[0][0] == 5 and ranges[-1][1] == 1005
+        assert all(a[1] == b[0] for a, b in zip(ranges, ranges[1:]))
+    q = shard_params(p, 2, 4, "tiles")
+    assert (q.shard_index, q.shard_count, q.spp, q.sample_begin) == (2, 4, 1000, 5)
+    with pytest.raises(ValueError):
+        shard_params(make_params(8, 8, 3), 0, 8, "samples")
+    with pytest.raises(ValueError):
+        shard_params(p, 4, 4, "samples")
