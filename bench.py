@@ -118,6 +118,15 @@ def main():
     kernel_ms = sum(a.elapsed_time(b) for a, b in events) / max(1, args.steps)
     image_checksum = float(buf.double().sum().item()) if rank == 0 else 0.0
 
+    # HBM bytes per launch of the dominant kernel from a committed PMC profile of this exact workload
+    # (rocprofv3 FETCH_SIZE / WRITE_SIZE passes; tools_profile.sh), null for any other workload
+    traffic = None
+    traffic_file = os.path.join(ROOT, "profiles", "r1", "traffic.json")
+    if (nx, ny, spp, world) == (1024, 1024, 1000, 1) and os.path.exists(traffic_file):
+        for name, t in json.load(open(traffic_file)).items():
+            if name.startswith("render_kernel"):
+                traffic = int(t["read_bytes"] + t["write_bytes"])
+
     # event counts of this rank's launch, from the counting build of the same kernel (untimed)
     roofline = None
     counts = None
@@ -128,7 +137,9 @@ def main():
         achieved = flops / (kernel_ms * 1e-3) / 1e12
         roofline = {
             "bound": "valu", "kernel": "render_kernel", "achieved": round(achieved, 3), "peak": VALU_PEAK_TFLOPS,
-            "unit": "TFLOP/s", "frac": round(achieved / VALU_PEAK_TFLOPS, 4), "traffic": None,
+            "unit": "TFLOP/s", "frac": round(achieved / VALU_PEAK_TFLOPS, 4), "traffic": traffic,
+            "traffic_note": "HBM bytes per launch (PMC, profiles/r1): the kernel writes one 12.6 MB partial image per sample "
+                            "chunk, added up by reduce_slabs_kernel; reads are 0.2 MB",
             "kernel_ms": round(kernel_ms, 3), "flops_per_launch": flops,
             "flops_per_path": round(flops / float(stats.paths), 1),
             "rays_per_path": round(stats.rays / float(stats.paths), 3),
