@@ -101,10 +101,11 @@ struct DevScene {
   const rt_material* materials;
   const rt_texture* textures;
   const rt_perlin* perlins;
-  int n_scan, n_prims, n_lights;
+  int n_scan, n_prims, n_dprims, n_lights;
   int mat_mask;  // bit RT_MAT_* set when a primitive or medium uses that material
   int textured;  // some material needs Texture::value (checker / noise)
   int flat;  // 1: the scan array holds leaves only (every skip is the next index)
+  const float4* leaf_box;  // per primitive: bmin, bmax of the scan leaf that holds it (two float4)
   // Stack traversal (scenes with more than a handful of leaves): the breadth-first
   // nodes with packed leaf information, and the objects their leaves refer to.  In
   // that mode `scan` holds only the ConstantMedium nodes, walked after the tree.
@@ -252,17 +253,21 @@ __device__ __forceinline__ Signs ray_signs(const RayF& r) {
   s.z = r.inv.z < 0.0f;
   return s;
 }
-__device__ __forceinline__ bool slab_test(const ScanNode& n, const RayF& r, const Signs& sg, float t_min, float t_max, float best_t) {
-  float t0 = (n.bmin[0] - r.o.x) * r.inv.x, t1 = (n.bmax[0] - r.o.x) * r.inv.x;
+__device__ __forceinline__ bool slab_box(float x0, float y0, float z0, float x1, float y1, float z1, const RayF& r, const Signs& sg,
+                                         float t_min, float t_max, float best_t) {
+  float t0 = (x0 - r.o.x) * r.inv.x, t1 = (x1 - r.o.x) * r.inv.x;
   t_min = fmaxf(sg.x ? t1 : t0, t_min);
   t_max = fminf(sg.x ? t0 : t1, t_max);
-  t0 = (n.bmin[1] - r.o.y) * r.inv.y; t1 = (n.bmax[1] - r.o.y) * r.inv.y;
+  t0 = (y0 - r.o.y) * r.inv.y; t1 = (y1 - r.o.y) * r.inv.y;
   t_min = fmaxf(sg.y ? t1 : t0, t_min);
   t_max = fminf(sg.y ? t0 : t1, t_max);
-  t0 = (n.bmin[2] - r.o.z) * r.inv.z; t1 = (n.bmax[2] - r.o.z) * r.inv.z;
+  t0 = (z0 - r.o.z) * r.inv.z; t1 = (z1 - r.o.z) * r.inv.z;
   t_min = fmaxf(sg.z ? t1 : t0, t_min);
   t_max = fminf(sg.z ? t0 : t1, t_max);
   return !(t_max <= t_min) & !(t_min > best_t);
+}
+__device__ __forceinline__ bool slab_test(const ScanNode& n, const RayF& r, const Signs& sg, float t_min, float t_max, float best_t) {
+  return slab_box(n.bmin[0], n.bmin[1], n.bmin[2], n.bmax[0], n.bmax[1], n.bmax[2], r, sg, t_min, t_max, best_t);
 }
 
 // XYRect/XZRect/YZRect::hit (hitable.rs:163-173 and twins).  C is the fixed
@@ -383,8 +388,10 @@ __device__ __forceinline__ int wave_min_i32(int v) {
 // Walks scan[begin, end) for the lanes with active == true, all 64 lanes of the
 // wave taking part in the control flow.  LEVEL 0 is the world frame; a K_OBJ_BVH
 // node re-enters at LEVEL 1 with the ray moved into the object's frame.  FLAT
-// means every node is a leaf, so no lane ever skips ahead.
-template <bool STATS, bool FLAT, bool MEDIA, int LEVEL>
+// means every node is a leaf, so no lane ever skips ahead.  DEFER (flat arrays
+// only) leaves the leaves' box tests out: trace_scan applies the winner's box
+// test afterwards.
+template <bool STATS, bool FLAT, bool MEDIA, int LEVEL, bool DEFER = false>
 __device__ __forceinline__ void scan_range(const DevScene& S, int begin, int end, bool active, const RayF& r, float t_min, float t_max,
                                            const PathRng& rng, Hit& best, Counters& cnt) {
   const Signs sg = ray_signs(r);
@@ -402,8 +409,11 @@ __device__ __forceinline__ void scan_range(const DevScene& S, int begin, int end
     // readfirstlane pins the index to an SGPR so the node arrives by scalar load.
     i = __builtin_amdgcn_readfirstlane(i);
     const ScanNode n = load_node(S.scan, i);
-    const bool on = act & slab_test(n, r, sg, t_min, t_max, best.t);
-    if (STATS) cnt.node_tests += act;
+    // Hierarchical arrays also skip a box entered beyond the best hit so far.  A flat
+    // array does not: its leaves are few, and a Cuboid's top face lies 0.01 above the
+    // cuboid's own box (hitable.rs:398-399), where that shortcut is not exact.
+    const bool on = DEFER ? act : (act & slab_test(n, r, sg, t_min, t_max, FLAT ? 3.402823466e+38f : best.t));
+    if (STATS && !DEFER) cnt.node_tests += act;
     if (!FLAT) lane_next = (act & !on) ? n.skip : lane_next;
     const int kind = n.kind;
     if (kind >= K_RECT_XY && kind <= K_RECT_YZ) {
@@ -586,9 +596,12 @@ __device__ __forceinline__ void trace_stack(const DevScene& S, unsigned* __restr
 // TRAV is chosen by the host per scene: each variant is its own kernel so the
 // register allocator only sees the code that scene can reach.
 enum { TRAV_SCAN = 0, TRAV_FLAT = 1, TRAV_STACK = 2 };
+#ifndef RT_FLAT_DEFER
+#define RT_FLAT_DEFER 1
+#endif
 template <bool STATS, int TRAV, bool MEDIA>
-__device__ __forceinline__ Hit trace_scan(const DevScene& S, unsigned* stk, bool active, const RayF& w, float t_min, float t_max,
-                                          const PathRng& rng, Counters& cnt) {
+__device__ __forceinline__ Hit trace_scan(const DevScene& S, unsigned* stk, const float4* leaf_box, bool active, const RayF& w, float t_min,
+                                          float t_max, const PathRng& rng, Counters& cnt) {
   Hit best;
   best.t = t_max;
   best.prim = -1;
@@ -596,6 +609,26 @@ __device__ __forceinline__ Hit trace_scan(const DevScene& S, unsigned* stk, bool
     if (active) trace_stack<STATS>(S, stk, w, t_min, t_max, best, cnt);
     // what is left in the scan array in this mode: the ConstantMedium nodes
     if (MEDIA && S.n_scan > 0) scan_range<STATS, true, true, 0>(S, 0, S.n_scan, active, w, t_min, t_max, rng, best, cnt);
+  } else if (TRAV == TRAV_FLAT && !MEDIA && RT_FLAT_DEFER) {
+    // A flat array of leaves: the nearest hit is the candidate with the smallest t,
+    // the later leaf winning a tie, among those whose leaf box the ray also passes
+    // (bvh.rs:198-203).  The box test almost never rejects a candidate whose own
+    // test accepted it (only rounding at a box face can), so take the winner over
+    // all candidates first and box-test it alone: if it passes it is also the
+    // winner among the box-tested candidates, each of which is one of the
+    // candidates it beat.  If it fails for any lane, the wave redoes the scan
+    // with every box test in place.
+    scan_range<STATS, true, false, 0, true>(S, 0, S.n_scan, active, w, t_min, t_max, rng, best, cnt);
+    const bool got = active & (best.prim >= 0);
+    const float4* lb = leaf_box + 2 * (got ? best.prim : 0);
+    const float4 b0 = lb[0], b1 = lb[1];
+    if (STATS) cnt.node_tests += got;
+    const bool ok = slab_box(b0.x, b0.y, b0.z, b1.x, b1.y, b1.z, w, ray_signs(w), t_min, t_max, 3.402823466e+38f);
+    if (__builtin_expect(__ballot(got & !ok) != 0ull, 0)) {
+      best.t = t_max;
+      best.prim = -1;
+      scan_range<STATS, true, false, 0, false>(S, 0, S.n_scan, active, w, t_min, t_max, rng, best, cnt);
+    }
   } else {
     scan_range<STATS, TRAV == TRAV_FLAT, MEDIA, 0>(S, 0, S.n_scan, active, w, t_min, t_max, rng, best, cnt);
   }
@@ -650,7 +683,7 @@ __global__ void __launch_bounds__(256) trace_kernel(DevScene S, const float* __r
     const RayF w = make_ray(f3(o[3 * at], o[3 * at + 1], o[3 * at + 2]), f3(d[3 * at], d[3 * at + 1], d[3 * at + 2]));
     Counters cnt;
     PathRng rng = {0u, 0u, 0u, 0u, 0u};  // a deterministic query takes no random numbers: media are skipped
-    const Hit h = trace_scan<false, TRAV, false>(S, stk, active, w, t_min, t_max, rng, cnt);
+    const Hit h = trace_scan<false, TRAV, false>(S, stk, S.leaf_box, active, w, t_min, t_max, rng, cnt);
     if (active) {
       prim_id[idx] = h.prim;
       t_out[idx] = h.prim >= 0 ? h.t : 0.0f;
@@ -782,8 +815,20 @@ __global__ void __launch_bounds__(64, (GENERAL || TRAV == TRAV_STACK) ? 4 : RT_R
   // once instead of waiting for the slowest wave of a larger group.
   __shared__ float acc[1][6][64];
   __shared__ unsigned stack_lds[TRAV == TRAV_STACK ? STACK_DEPTH * 64 : 64];
+  // A flat scene's primitive tables live in LDS (4 + 2 float4 per primitive, the
+  // launch sizes the array): a path vertex then costs no global memory access.
+  extern __shared__ float4 prim_lds[];
   unsigned* stk = stack_lds + (threadIdx.x & 63);
   const int lane = threadIdx.x & 63;
+  const float4* dprim_tab = (const float4*)S.dprims;
+  const float4* box_tab = S.leaf_box;
+  if (TRAV == TRAV_FLAT) {
+    for (int k = lane; k < S.n_dprims * 4; k += 64) prim_lds[k] = dprim_tab[k];
+    for (int k = lane; k < S.n_prims * 2; k += 64) prim_lds[S.n_dprims * 4 + k] = box_tab[k];
+    dprim_tab = prim_lds;
+    box_tab = prim_lds + S.n_dprims * 4;
+    __syncthreads();
+  }
   const int wib = 0;
   // One wave = one work item = (tile, sample chunk).  With more than one chunk
   // each item writes its partial sums to its own slab; reduce_slabs_kernel adds
@@ -889,12 +934,20 @@ __global__ void __launch_bounds__(64, (GENERAL || TRAV == TRAV_STACK) ? 4 : RT_R
     // ---- world.hit(r, 0.001, INFINITY), main.rs:166 ----
     if (STATS) cnt.rays += alive;
     const PathRng rng = {pixel_id, sample, (unsigned)depth, A.key0, A.key1};
-    const Hit h = trace_scan<STATS, TRAV, GENERAL>(S, stk, alive, ray, A.t_min, INFINITY, rng, cnt);
+    const Hit h = trace_scan<STATS, TRAV, GENERAL>(S, stk, box_tab, alive, ray, A.t_min, INFINITY, rng, cnt);
 
     // ---- color(), main.rs:165-209, one vertex; every lane runs it, dead lanes and
     // misses on primitive 0 with their results masked ----
     const bool hit = alive & (h.prim >= 0);
-    const DevPrim q = S.dprims[hit ? h.prim : 0];
+    DevPrim q;
+    {
+      const float4* src = dprim_tab + 4 * (hit ? h.prim : 0);
+      const float4 q0 = src[0], q1 = src[1], q2 = src[2], q3 = src[3];
+      __builtin_memcpy((char*)&q, &q0, 16);
+      __builtin_memcpy((char*)&q + 16, &q1, 16);
+      __builtin_memcpy((char*)&q + 32, &q2, 16);
+      __builtin_memcpy((char*)&q + 48, &q3, 16);
+    }
     const Surface sf = finalize_hit(q, ray, h.t);
     const int mat_type = (q.flags >> DP_MAT_SHIFT) & 7;
     F3 color = f3(q.color[0], q.color[1], q.color[2]);
@@ -1112,6 +1165,7 @@ struct rt_ctx {
   void* d_scan;
   void* d_prims;
   void* d_dprims;
+  void* d_leaf_box;
   void* d_bnodes;
   void* d_objects;
   void* d_materials;
@@ -1136,7 +1190,7 @@ int hip_fail(hipError_t e, const char* what) {
   } while (0)
 
 void free_scene(rt_ctx* ctx) {
-  void** ptrs[] = {&ctx->d_scan, &ctx->d_prims, &ctx->d_dprims, &ctx->d_bnodes, &ctx->d_objects, &ctx->d_materials, &ctx->d_textures, &ctx->d_perlins};
+  void** ptrs[] = {&ctx->d_scan, &ctx->d_prims, &ctx->d_dprims, &ctx->d_leaf_box, &ctx->d_bnodes, &ctx->d_objects, &ctx->d_materials, &ctx->d_textures, &ctx->d_perlins};
   for (size_t i = 0; i < sizeof(ptrs) / sizeof(ptrs[0]); ++i) {
     if (*ptrs[i]) (void)hipFree(*ptrs[i]);
     *ptrs[i] = nullptr;
@@ -1228,14 +1282,22 @@ int count_leaves(const rt_scene* s, int idx, int depth, std::vector<int>* memo) 
 // every ancestor's: dropping the interior tests changes no result, and for a
 // handful of leaves a wave of 64 incoherent rays would have visited them all anyway.
 const int kTreeletLeaves = 16;
+// A scene is run as "flat" when its scan array has no interior node and it has at
+// most this many primitives (96 bytes of LDS each in the render kernel).
+const int kFlatMaxPrims = 64;
 
 struct ScanBuilder {
   const rt_scene* s;
   std::vector<int> leaves;
   std::vector<ScanNode> out;
   std::vector<int> prim_obj;
+  std::vector<float> leaf_box;  // 8 floats per primitive: the box of the scan leaf that holds it
   std::vector<int> media;  // object index of each ConstantMedium, in scan order
   bool any_interior;
+  void set_leaf_box(int prim, const rt_node& n) {
+    float* b = &leaf_box[(size_t)prim * 8];
+    for (int c = 0; c < 3; ++c) { b[c] = n.bmin[c]; b[4 + c] = n.bmax[c]; }
+  }
 };
 
 // True when prims[first, first+count) is six rects in Cuboid::new's order.
@@ -1301,7 +1363,10 @@ int build_scan(ScanBuilder* B, int idx, bool in_sub, bool collapsed, bool tree_r
   const int ref = ~n.left;
   if (n.right > 0) {
     if (ref < 0 || ref + n.right > s->n_prims) return rt::set_error(RT_ERR_INVALID, "leaf primitive range out of bounds");
-    for (int k = ref; k < ref + n.right; ++k) B->prim_obj[k] = obj;
+    for (int k = ref; k < ref + n.right; ++k) {
+      B->prim_obj[k] = obj;
+      if (!in_sub) B->set_leaf_box(k, n);
+    }
     if (n.right == 1) {
       const rt_prim& q = s->prims[ref];
       const int type = q.type & RT_PRIM_TYPE_MASK;
@@ -1329,7 +1394,10 @@ int build_scan(ScanBuilder* B, int idx, bool in_sub, bool collapsed, bool tree_r
   const size_t at = B->out.size();
   if (ob.kind == RT_OBJ_LIST || ob.kind == RT_OBJ_MEDIUM) {
     const bool medium = ob.kind == RT_OBJ_MEDIUM;
-    for (int k = ob.first; k < ob.first + ob.count; ++k) B->prim_obj[k] = ref;
+    for (int k = ob.first; k < ob.first + ob.count; ++k) {
+      B->prim_obj[k] = ref;
+      B->set_leaf_box(k, n);
+    }
     sn.kind = medium ? K_MEDIUM : K_OBJ_LIST;
     sn.a = ob.first;
     sn.b = ob.count | box6_flag(s, ob.first, ob.count) | (ob.xform << 24);
@@ -1489,7 +1557,8 @@ int launch_render(rt_ctx* ctx, const rt_camera* cam, const rt_render_params* p, 
 #undef RT_ROW
   const int trav = ctx->dev.stack_mode ? TRAV_STACK : (ctx->dev.flat ? TRAV_FLAT : TRAV_SCAN);
   const RenderFn fn = table[(stats ? 12 : 0) + (d_sumsq ? 6 : 0) + trav * 2 + (ctx->general ? 1 : 0)];
-  hipLaunchKernelGGL(fn, grid, block, 0, stream, ctx->dev, dc, A, k_sum, k_sumsq, ctx->d_stats);
+  const size_t lds_bytes = trav == TRAV_FLAT ? ((size_t)ctx->dev.n_dprims * 4 + (size_t)ctx->dev.n_prims * 2) * sizeof(float4) : 0;
+  hipLaunchKernelGGL(fn, grid, block, lds_bytes, stream, ctx->dev, dc, A, k_sum, k_sumsq, ctx->d_stats);
   HIP_TRY(hipGetLastError());
   if (A.n_chunks > 1) {
     const size_t n4 = n / 4;
@@ -1547,6 +1616,7 @@ int rt_upload_scene(rt_ctx* ctx, const rt_scene* s) {
   B.s = s;
   B.leaves.assign((size_t)s->n_nodes, 0);
   B.prim_obj.assign((size_t)s->n_prims, -1);
+  B.leaf_box.assign((size_t)s->n_prims * 8, 0.0f);
   B.any_interior = false;
   rc = count_leaves(s, 0, 0, &B.leaves);
   if (rc < 0) return rc;
@@ -1616,6 +1686,7 @@ int rt_upload_scene(rt_ctx* ctx, const rt_scene* s) {
     d.ref_idx = m.ref_idx;
   }
   if ((rc = upload(&ctx->d_dprims, dprims.data(), dprims.size())) != RT_OK) return rc;
+  if ((rc = upload(&ctx->d_leaf_box, B.leaf_box.data(), B.leaf_box.size())) != RT_OK) return rc;
   if ((rc = upload(&ctx->d_bnodes, bnodes.data(), bnodes.size())) != RT_OK) return rc;
   if ((rc = upload(&ctx->d_objects, s->objects, (size_t)s->n_objects)) != RT_OK) return rc;
   if ((rc = upload(&ctx->d_materials, s->materials, (size_t)s->n_materials)) != RT_OK) return rc;
@@ -1626,7 +1697,9 @@ int rt_upload_scene(rt_ctx* ctx, const rt_scene* s) {
   d.scan = (const ScanNode*)ctx->d_scan;
   d.prims = (const rt_prim*)ctx->d_prims;
   d.dprims = (const DevPrim*)ctx->d_dprims;
-  d.flat = (B.any_interior && !stack_mode) ? 0 : 1;
+  d.leaf_box = (const float4*)ctx->d_leaf_box;
+  // flat: leaves only, and few enough primitives for the render kernel's LDS tables
+  d.flat = (!B.any_interior && !stack_mode && dprims.size() <= (size_t)kFlatMaxPrims) ? 1 : 0;
   d.bnodes = (const BNode*)ctx->d_bnodes;
   d.objects = (const rt_object*)ctx->d_objects;
   d.stack_mode = stack_mode ? 1 : 0;
@@ -1637,6 +1710,7 @@ int rt_upload_scene(rt_ctx* ctx, const rt_scene* s) {
   d.perlins = (const rt_perlin*)ctx->d_perlins;
   d.n_scan = (int)scan.size();
   d.n_prims = s->n_prims;
+  d.n_dprims = (int)dprims.size();
   d.n_lights = s->n_lights;
   if (s->n_lights > 0) d.light = s->lights[0];
   ctx->general = textured || !B.media.empty() || (mat_mask & ~((1 << RT_MAT_LAMBERTIAN) | (1 << RT_MAT_DIFFUSE_LIGHT))) != 0;

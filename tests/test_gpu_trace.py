@@ -42,6 +42,45 @@ def test_trace_against_f64_reference_arithmetic(gpu, orc, cornell):
     assert_t_close(t[hit].astype(np.float64), t64[hit], d[hit])
 
 
+def test_trace_cuboid_top_face_band(gpu, orc, cornell):
+    """Cuboid::new puts the top face 0.01 above the cuboid's own bounding box
+    (hitable.rs:398-399), so whether a ray that grazes it counts as a hit depends
+    on the box test of the node above it (bvh.rs:198-203).  Rays aimed into that
+    band, steep and grazing, near and across the face's edges, must agree with the
+    oracle bit for bit."""
+    gpu.upload_scene(cornell.flat)
+    rng = np.random.RandomState(11)
+    n = 60000
+    boxes = [((165.0, 165.0, 165.0), -18.0, (130.0, 0.0, 65.0)), ((165.0, 330.0, 165.0), 15.0, (265.0, 0.0, 295.0))]
+    which = rng.randint(0, 2, size=n)
+    lx = rng.uniform(-3.0, 168.0, size=n)
+    lz = rng.uniform(-3.0, 168.0, size=n)
+    edge = rng.rand(n) < 0.5  # half of the targets hug an edge of the face
+    lx = np.where(edge & (rng.rand(n) < 0.5), rng.choice([0.0, 165.0], size=n) + rng.randn(n) * 0.02, lx)
+    lz = np.where(edge & (rng.rand(n) < 0.5), rng.choice([0.0, 165.0], size=n) + rng.randn(n) * 0.02, lz)
+    tgt = np.zeros((n, 3))
+    for b, (p1, angle, off) in enumerate(boxes):
+        th = np.radians(angle)
+        m = which == b
+        ly = p1[1] + rng.uniform(-0.02, 0.03, size=m.sum())
+        tgt[m, 0] = np.cos(th) * lx[m] + np.sin(th) * lz[m] + off[0]
+        tgt[m, 1] = ly + off[1]
+        tgt[m, 2] = -np.sin(th) * lx[m] + np.cos(th) * lz[m] + off[2]
+    o = rng.rand(n, 3) * 555.0
+    o[:, 1] = np.where(rng.rand(n) < 0.5, tgt[:, 1] + rng.uniform(0.0, 0.5, size=n), rng.uniform(0.0, 555.0, size=n))  # grazing / any
+    o = o.astype(np.float32)
+    d = ((tgt - o) * rng.uniform(0.2, 2.0, size=(n, 1))).astype(np.float32)
+    prim, t, normal, p = gpu.trace_closest(o, d, want_normal=True, want_p=True)
+    oprim, ot, onormal, op = orc.trace_closest(cornell.flat, o, d, mode=orc.ORC_F32_FUSED, want_normal=True, want_p=True)
+    assert np.array_equal(prim, oprim), np.nonzero(prim != oprim)[0][:10]
+    assert np.array_equal(t, ot.astype(np.float32))
+    assert np.array_equal(normal, onormal.astype(np.float32))
+    assert np.array_equal(p, op.astype(np.float32))
+    # the band is really exercised: many rays end on a face whose normal is +y well above the floor
+    tops = (prim >= 0) & (normal[:, 1] > 0.5) & (p[:, 1] > 100.0)
+    assert tops.mean() > 0.1, tops.mean()
+
+
 def test_trace_finite_interval_and_empty_batch(gpu, orc, cornell):
     gpu.upload_scene(cornell.flat)
     o, d = cornell_ray_batch(cornell, 4096, seed=5)
