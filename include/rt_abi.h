@@ -267,6 +267,14 @@ int rt_trace_closest(rt_ctx* ctx, const float* o, const float* d, size_t n, floa
 int rt_tonemap(rt_ctx* ctx, const float* sum_rgb, int32_t nx, int32_t ny, int32_t spp_total,
                uint8_t* rgb8);
 
+/* Device self-test with no counterpart in the reference: the kernels replace
+ * the three divisions 1/d of Aabb::hit (src/bvh.rs:47) by a short reciprocal
+ * sequence that must equal the correctly rounded quotient.  This runs the
+ * sequence against the division for all 2^32 float bit patterns on the device
+ * and returns the number of inputs where they differ (0 is the only pass) and up
+ * to 16 example bit patterns (optional). */
+int rt_selftest_reciprocal(rt_ctx* ctx, uint64_t* mismatches, uint32_t* examples16_or_null);
+
 #ifdef __cplusplus
 }
 #endif

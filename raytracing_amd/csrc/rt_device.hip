@@ -146,11 +146,35 @@ __device__ __forceinline__ float dot3(F3 a, F3 b) { return fmaf(a.z, b.z, fmaf(a
 struct RayF {
   F3 o, d, inv;
 };
+
+// The correctly rounded reciprocal, 1.0f / x, in five instructions instead of the
+// dozen of the general division: the hardware estimate (1 ulp) and one Newton
+// step with single-rounding multiply-adds.  rt_selftest_reciprocal compares it
+// with the division for every one of the 2^32 bit patterns on the device it runs
+// on; the inputs outside RCP_LO..RCP_HI in magnitude (and zero, infinity, NaN),
+// where the step's residual is not representable, take the division itself.
+#define RT_RCP_LO 1.0e-30f
+#define RT_RCP_HI 1.0e+30f
+__device__ __forceinline__ float rcp_newton(float x) {
+  const float r = __builtin_amdgcn_rcpf(x);
+  const float e = fmaf(-x, r, 1.0f);
+  return fmaf(e, r, r);
+}
+__device__ __forceinline__ bool rcp_in_range(float x) {
+  const float a = fabsf(x);
+  return (a >= RT_RCP_LO) & (a <= RT_RCP_HI);
+}
+__device__ __forceinline__ float exact_rcp(float x) {
+  float r = rcp_newton(x);
+  // wave-uniform: the division is only compiled into a branch no ordinary ray takes
+  if (__builtin_expect(__ballot(!rcp_in_range(x)) != 0ull, 0)) r = rcp_in_range(x) ? r : 1.0f / x;
+  return r;
+}
 __device__ __forceinline__ RayF make_ray(F3 o, F3 d) {
   RayF r;
   r.o = o;
   r.d = d;
-  r.inv = f3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+  r.inv = f3(exact_rcp(d.x), exact_rcp(d.y), exact_rcp(d.z));
   return r;
 }
 
@@ -170,8 +194,8 @@ __device__ __forceinline__ RayF to_object_frame(const RayF& w, int xform, float 
   r.d.z = ro ? fmaf(sin_t, d.x, cos_t * d.z) : d.z;
   if (WANT_INV) {
     // d is unchanged without a rotation, so 1/d is the same value either way.
-    r.inv.x = 1.0f / r.d.x;
-    r.inv.z = 1.0f / r.d.z;
+    r.inv.x = exact_rcp(r.d.x);
+    r.inv.z = exact_rcp(r.d.z);
   }
   return r;
 }
@@ -1123,6 +1147,32 @@ __global__ void __launch_bounds__(64, (GENERAL || TRAV == TRAV_STACK) ? 4 : RT_R
 }
 
 // ---------------------------------------------------------------------------
+// selftest_rcp_kernel: exact_rcp against the correctly rounded division for all
+// 2^32 inputs.  counts[0] = mismatching inputs, counts[1] = in-range inputs
+// whose Newton step alone (no fallback) mismatches, bad[0..15] = examples.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) selftest_rcp_kernel(unsigned long long* __restrict__ counts, unsigned* __restrict__ bad) {
+  const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+  unsigned mism = 0, mism_newton = 0;
+  for (unsigned long long v = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; v < (1ull << 32); v += stride) {
+    const float x = __uint_as_float((unsigned)v);
+    const float want = 1.0f / x;
+    const float got = exact_rcp(x);
+    const bool same = (__float_as_uint(want) == __float_as_uint(got)) | ((want != want) & (got != got));
+    const float nw = rcp_newton(x);
+    const bool same_n = (__float_as_uint(want) == __float_as_uint(nw)) | ((want != want) & (nw != nw));
+    if (!same) {
+      const unsigned slot = mism < 1 ? atomicAdd(&bad[16], 1u) : 16u;
+      if (slot < 16u) bad[slot] = (unsigned)v;
+      ++mism;
+    }
+    if (!same_n && rcp_in_range(x)) ++mism_newton;
+  }
+  if (mism) atomicAdd(&counts[0], (unsigned long long)mism);
+  if (mism_newton) atomicAdd(&counts[1], (unsigned long long)mism_newton);
+}
+
+// ---------------------------------------------------------------------------
 // reduce_slabs_kernel: out[i] = slab0[i] + slab1[i] + ... in that order.
 // ---------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) reduce_slabs_kernel(const float4* __restrict__ slabs, size_t n4, int n_slabs, float4* __restrict__ out) {
@@ -1801,6 +1851,33 @@ int rt_trace_closest(rt_ctx* ctx, const float* o, const float* d, size_t n, floa
   for (size_t i = 0; i < 6; ++i)
     if (ptrs[i]) (void)hipFree(ptrs[i]);
   if (e != hipSuccess) return hip_fail(e, "rt_trace_closest");
+  return RT_OK;
+}
+
+int rt_selftest_reciprocal(rt_ctx* ctx, uint64_t* mismatches, uint32_t* examples16) {
+  if (!ctx || !mismatches) return rt::set_error(RT_ERR_INVALID, "rt_selftest_reciprocal: null argument");
+  HIP_TRY(hipSetDevice(ctx->device));
+  unsigned long long* d_counts = nullptr;
+  unsigned* d_bad = nullptr;
+  hipError_t e = hipMalloc((void**)&d_counts, 2 * sizeof(unsigned long long));
+  if (e == hipSuccess) e = hipMalloc((void**)&d_bad, 17 * sizeof(unsigned));
+  if (e == hipSuccess) e = hipMemset(d_counts, 0, 2 * sizeof(unsigned long long));
+  if (e == hipSuccess) e = hipMemset(d_bad, 0, 17 * sizeof(unsigned));
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(selftest_rcp_kernel, dim3(256 * 32), dim3(256), 0, 0, d_counts, d_bad);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipDeviceSynchronize();
+  unsigned long long counts[2] = {0, 0};
+  unsigned bad[17];
+  std::memset(bad, 0, sizeof(bad));
+  if (e == hipSuccess) e = hipMemcpy(counts, d_counts, sizeof(counts), hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = hipMemcpy(bad, d_bad, sizeof(bad), hipMemcpyDeviceToHost);
+  if (d_counts) (void)hipFree(d_counts);
+  if (d_bad) (void)hipFree(d_bad);
+  if (e != hipSuccess) return hip_fail(e, "rt_selftest_reciprocal");
+  mismatches[0] = counts[0] + counts[1];
+  if (examples16) std::memcpy(examples16, bad, 16 * sizeof(unsigned));
   return RT_OK;
 }
 

@@ -85,6 +85,16 @@ class Renderer(object):
         check(_lib.lib().rt_tonemap(self._ctx, a.ctypes.data, nx, ny, spp_total, out.ctypes.data))
         return out
 
+    def selftest_reciprocal(self):
+        """Runs the kernels' reciprocal sequence against the correctly rounded
+        division for all 2^32 float bit patterns on the device.  Returns
+        (mismatch count, up to 16 example bit patterns)."""
+        import ctypes as C
+        count = C.c_uint64(0)
+        bad = (C.c_uint32 * 16)()
+        check(_lib.lib().rt_selftest_reciprocal(self._ctx, C.byref(count), bad))
+        return int(count.value), [int(b) for b in bad]
+
 
 def render_image(scene, camera, world, nx, ny, ns, seed=0x5EED0001, light_shape=None, device_id=0):
     """main(): flatten `world`, render ns samples per pixel, return the 8-bit

@@ -42,6 +42,15 @@ def test_trace_against_f64_reference_arithmetic(gpu, orc, cornell):
     assert_t_close(t[hit].astype(np.float64), t64[hit], d[hit])
 
 
+def test_reciprocal_sequence_equals_division_for_every_float(gpu):
+    """The kernels compute 1/d (bvh.rs:47) with a hardware estimate plus one
+    Newton step instead of the full division.  The bit-exact parity above rests on
+    that being the correctly rounded quotient, so the device checks it for all
+    2^32 inputs."""
+    mismatches, examples = gpu.selftest_reciprocal()
+    assert mismatches == 0, [hex(e) for e in examples if e]
+
+
 def test_trace_cuboid_top_face_band(gpu, orc, cornell):
     """Cuboid::new puts the top face 0.01 above the cuboid's own bounding box
     (hitable.rs:398-399), so whether a ray that grazes it counts as a hit depends
