@@ -920,8 +920,14 @@ __global__ void __launch_bounds__(64, (GENERAL || TRAV == TRAV_STACK) ? 4 : RT_R
       continue;
     }
 
+    // The empty asm makes the key opaque to the optimiser once per iteration.  Without
+    // it the ten round keys (key + round * constant) are computed before the loop and
+    // held in twenty scalar registers for its whole life, which this kernel does not
+    // have to spare; with it they are nine scalar additions per call.
+    unsigned key0 = A.key0, key1 = A.key1;
+    asm volatile("" : "+s"(key0), "+s"(key1));
     // ---- the one Philox call of this vertex: counter (pixel, sample, depth, 0) ----
-    const U4 w = philox4x32_10(pixel_id, sample, (unsigned)depth, 0u, A.key0, A.key1);
+    const U4 w = philox4x32_10(pixel_id, sample, (unsigned)depth, 0u, key0, key1);
 
     // ---- camera ray of the fresh lanes (main.rs:102-105, camera.rs:53-62) ----
     if (__ballot(fresh) != 0ull) {
@@ -935,7 +941,7 @@ __global__ void __launch_bounds__(64, (GENERAL || TRAV == TRAV_STACK) ? 4 : RT_R
         unsigned attempt = 0;
         bool looking = fresh;
         while (__ballot(looking) != 0ull) {
-          const U4 lw = philox4x32_10(pixel_id, sample, 0u, 1u + attempt, A.key0, A.key1);
+          const U4 lw = philox4x32_10(pixel_id, sample, 0u, 1u + attempt, key0, key1);
           const float dx = 2.0f * u01(lw.x) - 1.0f, dy = 2.0f * u01(lw.y) - 1.0f;
           const bool ok = looking & (fmaf(dy, dy, dx * dx) < 1.0f);
           rdx = ok ? cam.lens_radius * dx : rdx;
@@ -957,7 +963,7 @@ __global__ void __launch_bounds__(64, (GENERAL || TRAV == TRAV_STACK) ? 4 : RT_R
 
     // ---- world.hit(r, 0.001, INFINITY), main.rs:166 ----
     if (STATS) cnt.rays += alive;
-    const PathRng rng = {pixel_id, sample, (unsigned)depth, A.key0, A.key1};
+    const PathRng rng = {pixel_id, sample, (unsigned)depth, key0, key1};
     const Hit h = trace_scan<STATS, TRAV, GENERAL>(S, stk, box_tab, alive, ray, A.t_min, INFINITY, rng, cnt);
 
     // ---- color(), main.rs:165-209, one vertex; every lane runs it, dead lanes and
@@ -1050,7 +1056,7 @@ __global__ void __launch_bounds__(64, (GENERAL || TRAV == TRAV_STACK) ? 4 : RT_R
         bool looking = is_metal | is_iso;
         unsigned attempt = 0;
         while (__ballot(looking) != 0ull) {
-          const U4 sw = philox4x32_10(pixel_id, sample, (unsigned)depth, 256u + attempt, A.key0, A.key1);
+          const U4 sw = philox4x32_10(pixel_id, sample, (unsigned)depth, 256u + attempt, key0, key1);
           const F3 c = f3(2.0f * u01(sw.x) - 1.0f, 2.0f * u01(sw.y) - 1.0f, 2.0f * u01(sw.z) - 1.0f);
           const bool ok = looking & (dot3(c, c) < 1.0f);
           rs = sel3(ok, c, rs);
