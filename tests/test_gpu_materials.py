@@ -113,3 +113,63 @@ def test_trace_skips_media_and_sees_general_scenes(gpu, orc):
         assert np.array_equal(prim, oprim)
         assert np.array_equal(t, ot.astype(np.float32))
         assert prim.max() < flat.n_prims
+
+
+def _sphere_field(n, seed, glass_and_metal):
+    """n small spheres over a big ground sphere, a rect light above them."""
+    rng = np.random.RandomState(seed)
+    items = [S.Sphere.new(S.vec3(0.0, -1000.0, 0.0), 1000.0, S.Lambertian.new_from_color(S.vec3(0.5, 0.5, 0.5)))]
+    for k in range(n):
+        c = S.vec3(float(rng.uniform(-6, 6)), 0.3, float(rng.uniform(-6, 6)))
+        pick = rng.rand() if glass_and_metal else 0.0
+        if pick < 0.7:
+            m = S.Lambertian.new_from_color(S.vec3(*(rng.rand(3) * rng.rand(3))))
+        elif pick < 0.85:
+            m = S.Metal.new(S.vec3(*(0.5 * (1 + rng.rand(3)))), float(0.5 * rng.rand()))
+        else:
+            m = S.Dielectric.new(1.5)
+        items.append(S.Sphere.new(c, 0.3, m))
+    # facing down, like the Cornell box's lamp (scenes.rs:310-317)
+    items.append(S.FlipNormals.new_xz(S.XZRect.new(-3.0, 3.0, -3.0, 3.0, 6.0, S.DiffuseLight.new(S.Texture.new_constant(S.scalar(6.0))))))
+    cam = S.Camera.new(S.vec3(10.0, 3.0, 6.0), S.vec3(0.0, 0.3, 0.0), S.vec3(0.0, 1.0, 0.0), 35.0, 1.5, 0.0, 10.0)
+    return cam, S.HitableList.new(items)
+
+
+def test_large_tree_render_lambertian(gpu, orc):
+    """150 spheres: more leaves than a flat array takes, so the per-lane stack
+    traversal runs under the Lambertian-only build of the render kernel, with the
+    MixturePDF sampling the rect light."""
+    with Scene(21) as sc:
+        cam, world = _sphere_field(150, 5, glass_and_metal=False)
+        sc.light_xz_rect(-3.0, 3.0, -3.0, 3.0, 6.0)
+        flat = sc.flatten(world)
+        assert flat.n_nodes > 64
+        _compare(gpu, orc, flat, cam, 60, 40, 64, same_frac=0.9)
+
+
+def test_large_tree_render_all_materials(gpu, orc):
+    """The same field with metal and glass spheres and the gradient sky: stack
+    traversal under the general build."""
+    with Scene(22) as sc:
+        cam, world = _sphere_field(150, 6, glass_and_metal=True)
+        flat = sc.flatten(world)
+        _compare(gpu, orc, flat, cam, 60, 40, 64, sky=_lib.RT_SKY_GRADIENT, same_frac=0.8)
+
+
+def test_long_primitive_list_render(gpu, orc):
+    """One Translate(RotateY(HitableList)) of 80 rects: a single leaf with more
+    primitives than the flat layout's LDS tables take, so the hierarchical scan
+    runs it (wave-uniform loop over the list)."""
+    with Scene(23) as sc:
+        cam, world0 = scenes.cornell_box_scene(1.0)
+        white = S.Lambertian.new_from_color(S.vec3(0.73, 0.73, 0.73))
+        rng = np.random.RandomState(2)
+        slats = []
+        for k in range(80):
+            x0, z0 = float(rng.uniform(0, 140)), float(rng.uniform(0, 140))
+            slats.append(S.XZRect.new(x0, x0 + 25.0, z0, z0 + 25.0, float(5.0 + 4.0 * k), white))
+        blinds = S.Translate.new(S.RotateY.new(S.HitableList.new(slats), 20.0), S.vec3(200.0, 0.0, 150.0))
+        sc.light_xz_rect(*scenes.MAIN_RS_LIGHT_SHAPE)
+        flat = sc.flatten(S.HitableList.new(world0.list[:6] + [blinds]))
+        assert flat.n_prims > 64
+        _compare(gpu, orc, flat, cam, 48, 48, 64, same_frac=0.9)

@@ -133,3 +133,59 @@ def test_render_argument_errors(gpu, cornell):
         with pytest.raises(RtError) as e:
             gpu.render(cornell.camera, bad)
         assert e.value.code == _lib.RT_ERR_INVALID
+
+
+def test_render_degenerate_sizes_and_depths(gpu, orc, cornell):
+    """One pixel, one sample, ragged tiles, max_depth 0 (camera rays only: no
+    random direction is ever drawn, so the image must equal the oracle's to fp32
+    rounding everywhere)."""
+    gpu.upload_scene(cornell.flat)
+    cam = cornell.camera
+    for nx, ny, spp in ((1, 1, 1), (1, 1, 65), (7, 3, 5), (9, 17, 33)):
+        p = make_params(nx, ny, spp, seed=17)
+        s, stats = gpu.render(cam, p, want_stats=True)
+        o, _ = orc.render(cornell.flat, cam.c, p, mode=orc.ORC_F32_FUSED)
+        assert s.shape == (ny, nx, 3) and stats.paths == nx * ny * spp
+        assert np.isfinite(s).all()
+        assert np.isclose(s, o, rtol=2e-4, atol=1e-4).mean() > 0.9
+    p = make_params(64, 64, 4, seed=9, max_depth=0)
+    s, stats = gpu.render(cam, p, want_stats=True)
+    o, _, ostats = orc.render(cornell.flat, cam.c, p, mode=orc.ORC_F32_FUSED, want_stats=True)
+    assert stats.rays == stats.paths == ostats.rays  # nothing scatters
+    assert stats.shade_events == 0
+    assert np.isclose(s, o, rtol=1e-6, atol=0).mean() > 0.995  # a ray on the light's edge may fall either way
+    assert s.max() > 0  # the light is in view
+
+
+def test_render_sample_chunks_equal_separate_launches(gpu, cornell):
+    """A launch that splits each tile's samples over several waves (chunks of at
+    least 32 samples, partial images added in a fixed order) gives what separate
+    launches over the same sample ranges give."""
+    gpu.upload_scene(cornell.flat)
+    cam = cornell.camera
+    nx, ny, spp = 40, 24, 256  # 15 tiles: the launch uses 8 chunks of 32 samples
+    whole = gpu.render(cam, make_params(nx, ny, spp, seed=12))
+    parts = sum(gpu.render(cam, make_params(nx, ny, 32, sample_begin=32 * k, seed=12)).astype(np.float64) for k in range(8))
+    assert np.allclose(whole, parts, rtol=1e-5, atol=1e-5)
+    # spp that is not a multiple of the chunk size, and second moments through the same path
+    s, s2 = gpu.render(cam, make_params(nx, ny, 100, seed=12), want_sumsq=True)
+    a, a2 = gpu.render(cam, make_params(nx, ny, 60, seed=12), want_sumsq=True)
+    b, b2 = gpu.render(cam, make_params(nx, ny, 40, sample_begin=60, seed=12), want_sumsq=True)
+    assert np.allclose(s, a + b, rtol=1e-5, atol=1e-5)
+    assert np.allclose(s2, a2 + b2, rtol=1e-5, atol=1e-4)
+
+
+def test_render_without_light_shape_uses_cosine_pdf_alone(gpu, orc, cornell):
+    """No light shape: color() samples CosinePDF only (pdf.rs:8-31)."""
+    from raytracing_amd import Scene, scenes
+    with Scene(3) as sc:
+        cam, world = scenes.cornell_box_scene(1.0)
+        flat = sc.flatten(world)
+        assert flat.n_lights == 0
+        gpu.upload_scene(flat)
+        p = make_params(48, 48, 32, seed=21)
+        s, stats = gpu.render(cam, p, want_stats=True)
+        o, _ = orc.render(flat, cam.c, p, mode=orc.ORC_F32_FUSED)
+        assert stats.light_tests == 0
+        assert np.isclose(s, o, rtol=2e-4, atol=1e-4).mean() > 0.97
+        assert abs(s.sum() - o.sum()) / o.sum() < 5e-3
