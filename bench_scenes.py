@@ -49,6 +49,8 @@ def main():
     ap.add_argument("--cpu-spp", type=int, default=0, help="also time the f64 oracle at this many spp (8 threads)")
     args = ap.parse_args()
 
+    import torch
+    torch.cuda.set_device(0)  # torch first: it brings up the HIP runtime the library then shares
     from raytracing_amd import Renderer, Scene, make_params
     t0 = time.perf_counter()
     sc = Scene(0x5EED0000)
@@ -67,12 +69,25 @@ def main():
         if best is None or stats.kernel_ms < best.kernel_ms:
             best = stats
     paths = args.nx * args.ny * args.spp
+    # the production build of the kernel (no event counters), device buffers, HIP events on the launch stream
+    dev = torch.device("cuda", 0)
+    buf = torch.empty(args.ny * args.nx * 3, dtype=torch.float32, device=dev)
+    stream = torch.cuda.current_stream(dev)
+    prod_ms = None
+    for _ in range(args.reps + 1):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        r.render_device(cam, p, buf.data_ptr(), None, stream.cuda_stream)
+        e1.record(stream)
+        torch.cuda.synchronize(dev)
+        ms = e0.elapsed_time(e1)
+        prod_ms = ms if prod_ms is None else min(prod_ms, ms)
     line = {
         "scene": args.scene, "nx": args.nx, "ny": args.ny, "spp": args.spp, "nodes": flat.n_nodes, "prims": flat.n_prims,
-        "build_s": round(t_build, 2), "kernel_ms": round(best.kernel_ms, 3),
-        "Mpaths_per_s": round(paths / best.kernel_ms / 1e3, 2), "Mrays_per_s": round(best.rays / best.kernel_ms / 1e3, 2),
+        "build_s": round(t_build, 2), "kernel_ms": round(prod_ms, 3), "counting_kernel_ms": round(best.kernel_ms, 3),
+        "Mpaths_per_s": round(paths / prod_ms / 1e3, 2), "Mrays_per_s": round(best.rays / prod_ms / 1e3, 2),
         "rays_per_path": round(best.rays / float(paths), 3), "node_tests_per_ray": round(best.node_tests / float(best.rays), 2),
-        "note": "kernel_ms is the event-counting build of the kernel (a few percent slower than the production build)",
+        "note": "kernel_ms times the production build; the event counts come from a separate launch of the counting build",
     }
     if args.cpu_spp > 0:
         from oracle import binding as orc

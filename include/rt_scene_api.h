@@ -54,6 +54,11 @@ int rtb_bvh_node(rt_builder* b, const int* hitables, int n);
 
 /* The light shape color() hands to HitablePDF (src/main.rs:177-178): an XZRect. */
 int rtb_light_xz_rect(rt_builder* b, double x0, double x1, double z0, double z1, double k);
+/* The same, read off the scene instead of typed in again: the first item of `world_list` that is an XZRect
+ * (bare or under FlipNormals) with a DiffuseLight material becomes the light shape, replacing any set before.
+ * Returns how many such items the list holds (0: nothing changed).  For the Cornell box this registers exactly
+ * the numbers src/main.rs:178 hard-codes, which are those of src/scenes.rs:310-317. */
+int rtb_light_from_world(rt_builder* b, int world_list);
 
 /* Builds the world BvhNode over the items of `world_list` (src/main.rs:85-90)
  * and flattens.  *out points into memory owned by the builder, valid until the

@@ -155,6 +155,7 @@ def lib():
     sig("rtb_hitable_list", C.c_int, vp, C.POINTER(C.c_int), C.c_int)
     sig("rtb_bvh_node", C.c_int, vp, C.POINTER(C.c_int), C.c_int)
     sig("rtb_light_xz_rect", C.c_int, vp, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double)
+    sig("rtb_light_from_world", C.c_int, vp, C.c_int)
     sig("rtb_flatten", C.c_int, vp, C.c_int, C.POINTER(rt_scene))
     _lib = L
     return L

@@ -585,6 +585,26 @@ int rtb_light_xz_rect(rt_builder* b, double x0, double x1, double z0, double z1,
   return (int)b->tables.lights.size() - 1;
 }
 
+int rtb_light_from_world(rt_builder* b, int world_list) {
+  if (bad_hitable(b, world_list) || b->hitables[world_list]->kind() != rt::Hitable::HITABLE_LIST)
+    return rt::set_error(RT_ERR_INVALID, "rtb_light_from_world: world must be a HitableList handle");
+  const rt::HitableList* world = static_cast<const rt::HitableList*>(b->hitables[world_list].get());
+  int found = 0;
+  for (const rt::HitablePtr& h : world->list) {
+    const rt::Rect* rect = nullptr;
+    if (h->kind() == rt::Hitable::XZ_RECT) rect = static_cast<const rt::Rect*>(h.get());
+    else if (h->kind() == rt::Hitable::FLIP_NORMALS) rect = static_cast<const rt::FlipNormals*>(h.get())->rect.get();
+    if (!rect || rect->axis != 1) continue;
+    if (b->tables.materials[(size_t)rect->material.id].type != RT_MAT_DIFFUSE_LIGHT) continue;
+    if (found == 0) {
+      b->tables.lights.clear();
+      (void)rtb_light_xz_rect(b, rect->a0, rect->a1, rect->b0, rect->b1, rect->k);
+    }
+    ++found;
+  }
+  return found;
+}
+
 int rtb_flatten(rt_builder* b, int world_list, rt_scene* out) {
   if (!out) return rt::set_error(RT_ERR_INVALID, "rtb_flatten: null out");
   if (bad_hitable(b, world_list) || b->hitables[world_list]->kind() != rt::Hitable::HITABLE_LIST)

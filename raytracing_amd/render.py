@@ -96,10 +96,11 @@ class Renderer(object):
         return int(count.value), [int(b) for b in bad]
 
 
-def render_image(scene, camera, world, nx, ny, ns, seed=0x5EED0001, light_shape=None, device_id=0):
+def render_image(scene, camera, world, nx, ny, ns, seed=0x5EED0001, light_shape=None, device_id=0, png_path=None):
     """main(): flatten `world`, render ns samples per pixel, return the 8-bit
-    image (main.rs:65-155).  `light_shape` = (x0, x1, z0, z1, k) is the XZRect
-    color() samples (main.rs:177-178); None renders with CosinePDF alone."""
+    image (main.rs:65-155) and, with `png_path`, write it as the reference does
+    (main.rs:157-160).  `light_shape` = (x0, x1, z0, z1, k) is the XZRect color()
+    samples (main.rs:177-178); None renders with CosinePDF alone."""
     if light_shape is not None:
         scene.light_xz_rect(*light_shape)
     flat = scene.flatten(world)
@@ -107,6 +108,10 @@ def render_image(scene, camera, world, nx, ny, ns, seed=0x5EED0001, light_shape=
     try:
         r.upload_scene(flat)
         sums = r.render(camera, make_params(nx, ny, ns, seed=seed))
-        return r.tonemap(sums, ns)
+        img = r.tonemap(sums, ns)
+        if png_path is not None:
+            from .png import write_png
+            write_png(png_path, img)
+        return img
     finally:
         r.close()

@@ -91,6 +91,13 @@ class Scene(object):
         """The XZRect that color() gives to HitablePDF (main.rs:177-178)."""
         return check(_lib.lib().rtb_light_xz_rect(self._b, x0, x1, z0, z1, k))
 
+    def light_from_world(self, world):
+        """Takes the light shape from the scene: the first emissive XZRect of
+        `world` (bare or under FlipNormals).  Returns how many there are."""
+        if world.scene is not self:
+            raise ValueError("world belongs to another Scene")
+        return check(_lib.lib().rtb_light_from_world(self._b, world.handle))
+
     def flatten(self, world):
         """BvhNode over world.list (main.rs:85-90), flattened to an rt_scene whose
         buffers live as long as this Scene does (or until the next flatten)."""

@@ -189,3 +189,29 @@ def test_render_without_light_shape_uses_cosine_pdf_alone(gpu, orc, cornell):
         assert stats.light_tests == 0
         assert np.isclose(s, o, rtol=2e-4, atol=1e-4).mean() > 0.97
         assert abs(s.sum() - o.sum()) / o.sum() < 5e-3
+
+
+def test_device_render_matches_reference_example_png(gpu, cornell, tmp_path):
+    """The reference's own example render, examples/cornell_box.png (600x600),
+    against the device path end to end: render 1000 samples per pixel, tonemap on
+    the device, write and re-read the PNG, compare 20x20 block means with the
+    fixture made from the reference's file.  The PNG's own sample count is not
+    recorded, so the bar is in 8-bit levels on block means."""
+    import os
+    from conftest import GOLDEN
+    from raytracing_amd.png import read_png, write_png
+    blocks_ref = np.load(os.path.join(GOLDEN, "cornell_box_png_blocks.npy")).astype(np.float64)
+    gpu.upload_scene(cornell.flat)
+    spp = 1000
+    s = gpu.render(cornell.camera, make_params(600, 600, spp, seed=0x5EED0001))
+    img = gpu.tonemap(s, spp)
+    path = str(tmp_path / "cornell_box.png")
+    write_png(path, img)
+    back = read_png(path)
+    assert np.array_equal(back, img)
+    blocks = back.astype(np.float64).reshape(30, 20, 30, 20, 3).mean(axis=(1, 3))
+    diff = blocks - blocks_ref
+    assert np.abs(diff).max() < 2.5, np.abs(diff).max()
+    assert np.sqrt((diff ** 2).mean()) < 0.5, np.sqrt((diff ** 2).mean())
+    assert abs(diff.mean()) < 0.3, diff.mean()
+    assert back[:10].max() == 0 and back[:, :10].max() == 0  # the black frame

@@ -156,3 +156,44 @@ def test_perlin_tables_follow_the_degenerate_shuffle():
         assert px == [(k + 1) & 255 for k in range(256)]
         v = np.array([list(p.ranvec[i]) for i in range(256)])
         assert np.allclose((v ** 2).sum(axis=1), 1.0, atol=1e-6)
+
+
+def test_png_round_trip(tmp_path):
+    """write_png writes what read_png (and any PNG reader) reads back; the file
+    layout is checked against a second, independent decoder when one is there."""
+    from raytracing_amd.png import read_png, write_png
+    rng = np.random.RandomState(0)
+    for shape in ((1, 1, 3), (7, 13, 3), (64, 40, 3)):
+        img = rng.randint(0, 256, size=shape).astype(np.uint8)
+        path = str(tmp_path / ("t%d.png" % shape[0]))
+        write_png(path, img)
+        assert np.array_equal(read_png(path), img)
+        try:
+            from PIL import Image
+        except ImportError:
+            continue
+        assert np.array_equal(np.asarray(Image.open(path).convert("RGB")), img)
+    with pytest.raises(ValueError):
+        write_png(str(tmp_path / "bad.png"), np.zeros((4, 4), dtype=np.uint8))
+
+
+def test_light_shape_read_from_the_scene_equals_the_hard_coded_one():
+    """color() hard-codes XZRect(213, 343, 227, 332, 554) (main.rs:178); the scene
+    builder finds the same rect in cornell_box_scene (scenes.rs:310-317)."""
+    from raytracing_amd.scenes import MAIN_RS_LIGHT_SHAPE
+    with Scene(1) as a, Scene(1) as b:
+        with a:
+            cam, world = cornell_box_scene(1.0)
+            a.light_xz_rect(*MAIN_RS_LIGHT_SHAPE)
+            fa = a.flatten(world)
+            typed = [fa.lights[0].f[k] for k in range(5)]
+        with b:
+            cam, world = cornell_box_scene(1.0)
+            assert b.light_from_world(world) == 1
+            fb = b.flatten(world)
+            assert fb.n_lights == 1 and fb.lights[0].type == 0  # RT_LIGHT_XZ_RECT
+            assert [fb.lights[0].f[k] for k in range(5)] == typed
+    with Scene(2) as c:
+        world = S.HitableList.new([S.Sphere.new(S.vec3(0, 0, 0), 1.0, S.Lambertian.new_from_color(S.vec3(0.5, 0.5, 0.5)))])
+        assert c.light_from_world(world) == 0
+        assert c.flatten(world).n_lights == 0
