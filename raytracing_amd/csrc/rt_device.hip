@@ -104,6 +104,7 @@ struct DevScene {
   int n_scan, n_prims, n_dprims, n_lights;
   int mat_mask;  // bit RT_MAT_* set when a primitive or medium uses that material
   int textured;  // some material needs Texture::value (checker / noise)
+  int has_spheres;
   int flat;  // 1: the scan array holds leaves only (every skip is the next index)
   const float4* leaf_box;  // per primitive: bmin, bmax of the scan leaf that holds it (two float4)
   // Stack traversal (scenes with more than a handful of leaves): the breadth-first
@@ -373,17 +374,19 @@ __device__ __forceinline__ void list_test(const rt_prim* __restrict__ prims, int
 // follow the node, fetched by two scalar loads, with no per-primitive dispatch.
 #define LIST_IS_BOX6 0x800000
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+// `k` is the pair's position in the list, a compile-time constant, so the selects
+// that track the winner need no register for it.
 template <int C, int A, int B>
-__device__ __forceinline__ void box_pair(const float* g, int prim0, bool lane_on, const RayF& r, float t_min, float& loc_t, int& loc_prim) {
+__device__ __forceinline__ void box_pair(const float* g, int k, bool lane_on, const RayF& r, float t_min, float& loc_t, int& loc_k) {
   float f[5] = {g[0], g[1], g[2], g[3], g[4]};
   float t;
   bool h = rect_test<C, A, B>(f, r, t_min, loc_t, t) & lane_on;
   loc_t = h ? t : loc_t;
-  loc_prim = h ? prim0 : loc_prim;
+  loc_k = h ? k : loc_k;
   f[4] = g[5];
   h = rect_test<C, A, B>(f, r, t_min, loc_t, t) & lane_on;
   loc_t = h ? t : loc_t;
-  loc_prim = h ? prim0 + 1 : loc_prim;
+  loc_k = h ? k + 1 : loc_k;
 }
 template <bool STATS>
 __device__ __forceinline__ void box6_test(const ScanNode* __restrict__ scan, int node, int first, bool lane_on, const RayF& r, float t_min,
@@ -394,14 +397,14 @@ __device__ __forceinline__ void box6_test(const ScanNode* __restrict__ scan, int
   __builtin_memcpy(&g[0], &v0, 64);
   __builtin_memcpy(&g[16], &v1, 8);
   float loc_t = t_max;
-  int loc_prim = -1;
-  box_pair<2, 0, 1>(&g[0], first, lane_on, r, t_min, loc_t, loc_prim);
-  box_pair<1, 0, 2>(&g[6], first + 2, lane_on, r, t_min, loc_t, loc_prim);
-  box_pair<0, 1, 2>(&g[12], first + 4, lane_on, r, t_min, loc_t, loc_prim);
+  int loc_k = -1;
+  box_pair<2, 0, 1>(&g[0], 0, lane_on, r, t_min, loc_t, loc_k);
+  box_pair<1, 0, 2>(&g[6], 2, lane_on, r, t_min, loc_t, loc_k);
+  box_pair<0, 1, 2>(&g[12], 4, lane_on, r, t_min, loc_t, loc_k);
   if (STATS) cnt.rect_tests += lane_on ? 6u : 0u;
-  const bool take = (loc_prim >= 0) & !(best.t < loc_t);
+  const bool take = (loc_k >= 0) & !(best.t < loc_t);
   best.t = take ? loc_t : best.t;
-  best.prim = take ? loc_prim : best.prim;
+  best.prim = take ? first + loc_k : best.prim;
 }
 
 __device__ __forceinline__ int wave_min_i32(int v) {
@@ -666,16 +669,18 @@ struct Surface {
 // The HitRecord fields color() needs (hitable.rs:175-182, 62-67), carried back
 // to the world frame by RotateY::hit (hitable.rs:521-528) and Translate::hit
 // (hitable.rs:442).  `q` is the hit primitive's DevPrim.
-__device__ __forceinline__ Surface finalize_hit(const DevPrim& q, const RayF& w, float t) {
+__device__ __forceinline__ Surface finalize_hit(const DevPrim& q, const RayF& w, float t, bool has_spheres) {
   Surface s;
   const int xform = (q.flags >> DP_XFORM_SHIFT) & 3;
   const RayF r = to_object_frame<false>(w, xform, q.sin_t, q.cos_t, q.off[0], q.off[1], q.off[2]);
   F3 p = f3(fmaf(t, r.d.x, r.o.x), fmaf(t, r.d.y, r.o.y), fmaf(t, r.d.z, r.o.z));
   const int type = q.flags & DP_TYPE_MASK;
-  const float inv_r = 1.0f / q.f[3];
   const float sgn = (q.flags & DP_FLIP) ? -1.0f : 1.0f;
   F3 nrm = f3(type == RT_PRIM_YZ_RECT ? sgn : 0.0f, type == RT_PRIM_XZ_RECT ? sgn : 0.0f, type == RT_PRIM_XY_RECT ? sgn : 0.0f);
-  nrm = sel3(type == RT_PRIM_SPHERE, f3((p.x - q.f[0]) * inv_r, (p.y - q.f[1]) * inv_r, (p.z - q.f[2]) * inv_r), nrm);
+  if (has_spheres) {  // wave-uniform: a property of the scene
+    const float inv_r = exact_rcp(q.f[3]);
+    nrm = sel3(type == RT_PRIM_SPHERE, f3((p.x - q.f[0]) * inv_r, (p.y - q.f[1]) * inv_r, (p.z - q.f[2]) * inv_r), nrm);
+  }
   nrm = sel3(type == DP_TYPE_MEDIUM, f3(1.0f, 0.0f, 0.0f), nrm);
   const bool ro = (xform & RT_XFORM_ROTATE_Y) != 0, tr = (xform & RT_XFORM_TRANSLATE) != 0;
   const F3 pl = p, nl = nrm;
@@ -715,7 +720,7 @@ __global__ void __launch_bounds__(256) trace_kernel(DevScene S, const float* __r
         Surface s;
         s.p = f3(0, 0, 0);
         s.normal = f3(0, 0, 0);
-        if (h.prim >= 0) s = finalize_hit(S.dprims[h.prim], w, h.t);
+        if (h.prim >= 0) s = finalize_hit(S.dprims[h.prim], w, h.t, S.has_spheres != 0);
         if (normal) { normal[3 * idx] = s.normal.x; normal[3 * idx + 1] = s.normal.y; normal[3 * idx + 2] = s.normal.z; }
         if (p_out) { p_out[3 * idx] = s.p.x; p_out[3 * idx + 1] = s.p.y; p_out[3 * idx + 2] = s.p.z; }
       }
@@ -978,7 +983,7 @@ __global__ void __launch_bounds__(64, (GENERAL || TRAV == TRAV_STACK) ? 4 : RT_R
       __builtin_memcpy((char*)&q + 32, &q2, 16);
       __builtin_memcpy((char*)&q + 48, &q3, 16);
     }
-    const Surface sf = finalize_hit(q, ray, h.t);
+    const Surface sf = finalize_hit(q, ray, h.t, S.has_spheres != 0);
     const int mat_type = (q.flags >> DP_MAT_SHIFT) & 7;
     F3 color = f3(q.color[0], q.color[1], q.color[2]);
     if (STATS) cnt.hits += hit;
@@ -1761,6 +1766,9 @@ int rt_upload_scene(rt_ctx* ctx, const rt_scene* s) {
   d.stack_mode = stack_mode ? 1 : 0;
   d.mat_mask = mat_mask;
   d.textured = textured;
+  d.has_spheres = 0;
+  for (int i = 0; i < s->n_prims; ++i)
+    if ((s->prims[i].type & RT_PRIM_TYPE_MASK) == RT_PRIM_SPHERE) d.has_spheres = 1;
   d.materials = (const rt_material*)ctx->d_materials;
   d.textures = (const rt_texture*)ctx->d_textures;
   d.perlins = (const rt_perlin*)ctx->d_perlins;
