@@ -849,6 +849,22 @@ __global__ void __launch_bounds__(64, (GENERAL || TRAV == TRAV_STACK) ? 4 : RT_R
   extern __shared__ float4 prim_lds[];
   unsigned* stk = stack_lds + (threadIdx.x & 63);
   const int lane = threadIdx.x & 63;
+  // The camera (19 floats, used once per path) lives in LDS rather than in scalar
+  // registers for the life of the kernel; every lane reads the same address.
+  __shared__ float cam_lds[20];
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      cam_lds[k] = cam.origin[k];
+      cam_lds[3 + k] = cam.llc[k];
+      cam_lds[6 + k] = cam.horizontal[k];
+      cam_lds[9 + k] = cam.vertical[k];
+      cam_lds[12 + k] = cam.u[k];
+      cam_lds[15 + k] = cam.v[k];
+    }
+    cam_lds[18] = cam.lens_radius;
+  }
+  const bool has_lens = cam.lens_radius != 0.0f;
   const float4* dprim_tab = (const float4*)S.dprims;
   const float4* box_tab = S.leaf_box;
   if (TRAV == TRAV_FLAT) {
@@ -940,26 +956,32 @@ __global__ void __launch_bounds__(64, (GENERAL || TRAV == TRAV_STACK) ? 4 : RT_R
       const int j = A.ny - 1 - (ty * 8 + (pix >> 3));
       const float u = ((float)px + (float)(w.x >> 16) * (1.0f / 65536.0f)) * A.inv_nx;
       const float v = ((float)j + (float)(w.x & 0xffffu) * (1.0f / 65536.0f)) * A.inv_ny;
+      // an index the optimiser cannot see through keeps these reads inside the loop
+      int c0 = 0;
+      asm volatile("" : "+v"(c0));
+      const float* cl = cam_lds + c0;
       float rdx = 0.0f, rdy = 0.0f;
-      if (cam.lens_radius != 0.0f) {
+      F3 offset = f3(0.0f, 0.0f, 0.0f);
+      if (has_lens) {
         // random_in_unit_disk, camera.rs:65-75: attempt a draws counter (pixel, sample, 0, 1+a)
+        const float lens_radius = cl[18];
         unsigned attempt = 0;
         bool looking = fresh;
         while (__ballot(looking) != 0ull) {
           const U4 lw = philox4x32_10(pixel_id, sample, 0u, 1u + attempt, key0, key1);
           const float dx = 2.0f * u01(lw.x) - 1.0f, dy = 2.0f * u01(lw.y) - 1.0f;
           const bool ok = looking & (fmaf(dy, dy, dx * dx) < 1.0f);
-          rdx = ok ? cam.lens_radius * dx : rdx;
-          rdy = ok ? cam.lens_radius * dy : rdy;
+          rdx = ok ? lens_radius * dx : rdx;
+          rdy = ok ? lens_radius * dy : rdy;
           looking &= !ok;
           ++attempt;
         }
+        offset = f3(fmaf(cl[15], rdy, cl[12] * rdx), fmaf(cl[16], rdy, cl[13] * rdx), fmaf(cl[17], rdy, cl[14] * rdx));
       }
-      const F3 offset = f3(fmaf(cam.v[0], rdy, cam.u[0] * rdx), fmaf(cam.v[1], rdy, cam.u[1] * rdx), fmaf(cam.v[2], rdy, cam.u[2] * rdx));
-      const F3 org = f3(cam.origin[0] + offset.x, cam.origin[1] + offset.y, cam.origin[2] + offset.z);
-      const F3 dir = f3(fmaf(v, cam.vertical[0], fmaf(u, cam.horizontal[0], cam.llc[0])) - cam.origin[0] - offset.x,
-                        fmaf(v, cam.vertical[1], fmaf(u, cam.horizontal[1], cam.llc[1])) - cam.origin[1] - offset.y,
-                        fmaf(v, cam.vertical[2], fmaf(u, cam.horizontal[2], cam.llc[2])) - cam.origin[2] - offset.z);
+      const F3 org = f3(cl[0] + offset.x, cl[1] + offset.y, cl[2] + offset.z);
+      const F3 dir = f3(fmaf(v, cl[9], fmaf(u, cl[6], cl[3])) - cl[0] - offset.x,
+                        fmaf(v, cl[10], fmaf(u, cl[7], cl[4])) - cl[1] - offset.y,
+                        fmaf(v, cl[11], fmaf(u, cl[8], cl[5])) - cl[2] - offset.z);
       ro = sel3(fresh, org, ro);
       rd = sel3(fresh, dir, rd);
       fresh = false;
