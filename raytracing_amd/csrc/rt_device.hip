@@ -175,7 +175,14 @@ __device__ __forceinline__ RayF make_ray(F3 o, F3 d) {
   RayF r;
   r.o = o;
   r.d = d;
-  r.inv = f3(exact_rcp(d.x), exact_rcp(d.y), exact_rcp(d.z));
+  r.inv = f3(rcp_newton(d.x), rcp_newton(d.y), rcp_newton(d.z));
+  // one range test for the three components
+  const float lo = fminf(fminf(fabsf(d.x), fabsf(d.y)), fabsf(d.z)), hi = fmaxf(fmaxf(fabsf(d.x), fabsf(d.y)), fabsf(d.z));
+  if (__builtin_expect(__ballot(!((lo >= RT_RCP_LO) & (hi <= RT_RCP_HI))) != 0ull, 0)) {
+    r.inv.x = rcp_in_range(d.x) ? r.inv.x : 1.0f / d.x;
+    r.inv.y = rcp_in_range(d.y) ? r.inv.y : 1.0f / d.y;
+    r.inv.z = rcp_in_range(d.z) ? r.inv.z : 1.0f / d.z;
+  }
   return r;
 }
 
@@ -183,10 +190,26 @@ __device__ __forceinline__ RayF make_ray(F3 o, F3 d) {
 // in the object's frame.  d.y, and so inv.y, is unchanged.  WANT_INV = false
 // skips the two reciprocals (the caller only needs o and d).  `xform` may differ
 // from lane to lane, so the two steps are selects, not branches.
-template <bool WANT_INV>
+template <bool WANT_INV, bool UNIFORM = false>
 __device__ __forceinline__ RayF to_object_frame(const RayF& w, int xform, float sin_t, float cos_t, float ox, float oy, float oz) {
   RayF r = w;
   const bool tr = (xform & RT_XFORM_TRANSLATE) != 0, ro = (xform & RT_XFORM_ROTATE_Y) != 0;
+  if (UNIFORM) {
+    // the whole wave is at the same object: branch instead of selecting
+    if (tr) r.o = f3(w.o.x - ox, w.o.y - oy, w.o.z - oz);
+    if (ro) {
+      const F3 o = r.o, d = r.d;
+      r.o.x = fmaf(cos_t, o.x, -(sin_t * o.z));
+      r.o.z = fmaf(sin_t, o.x, cos_t * o.z);
+      r.d.x = fmaf(cos_t, d.x, -(sin_t * d.z));
+      r.d.z = fmaf(sin_t, d.x, cos_t * d.z);
+      if (WANT_INV) {
+        r.inv.x = exact_rcp(r.d.x);
+        r.inv.z = exact_rcp(r.d.z);
+      }
+    }
+    return r;
+  }
   r.o = sel3(tr, f3(w.o.x - ox, w.o.y - oy, w.o.z - oz), w.o);
   const F3 o = r.o, d = r.d;
   r.o.x = ro ? fmaf(cos_t, o.x, -(sin_t * o.z)) : o.x;
@@ -299,6 +322,9 @@ __device__ __forceinline__ bool slab_test(const ScanNode& n, const RayF& r, cons
 // axis, A and B the in-plane axes in constructor order; f = a0,a1,b0,b1,k.  The
 // source's rejects are kept as written so a NaN passes them exactly as it does
 // there.  t = (k - o[C]) * (1/d[C]) replaces the source's division.
+#ifndef RT_RECT_MED3
+#define RT_RECT_MED3 1
+#endif
 template <int C, int A, int B>
 __device__ __forceinline__ bool rect_test(const float* f, const RayF& r, float t0, float t1, float& t_out) {
   const float oc = C == 0 ? r.o.x : (C == 1 ? r.o.y : r.o.z);
@@ -310,9 +336,18 @@ __device__ __forceinline__ bool rect_test(const float* f, const RayF& r, float t
   const float t = (f[4] - oc) * ic;
   const float a = fmaf(t, da, oa);
   const float b = fmaf(t, db, ob);
-  const bool miss = (t < t0) | (t > t1) | (a < f[0]) | (a > f[1]) | (b < f[2]) | (b > f[3]);
   t_out = t;
+#if RT_RECT_MED3
+  // x lies in [lo, hi] exactly when the median of the three is x (the bounds are
+  // ordered: rt_upload_scene refuses a rect with a0 > a1, the callers keep
+  // t0 <= t1).  A NaN x makes the median one of the bounds and the comparison
+  // unordered, which counts as inside, as the source's two rejects do.
+  const float mt = __builtin_amdgcn_fmed3f(t, t0, t1), ma = __builtin_amdgcn_fmed3f(a, f[0], f[1]), mb = __builtin_amdgcn_fmed3f(b, f[2], f[3]);
+  return !((mt < t) | (mt > t)) & !((ma < a) | (ma > a)) & !((mb < b) | (mb > b));
+#else
+  const bool miss = (t < t0) | (t > t1) | (a < f[0]) | (a > f[1]) | (b < f[2]) | (b > f[3]);
   return !miss;
+#endif
 }
 
 // Sphere::hit (hitable.rs:50-82): half-b quadratic, nearer root first, strict
@@ -469,7 +504,7 @@ __device__ __forceinline__ void scan_range(const DevScene& S, int begin, int end
     } else if (kind == K_OBJ_LIST || kind == K_OBJ_BVH) {
       if (LEVEL == 0) {
         if (__ballot(on) != 0ull) {
-          const RayF q = to_object_frame<true>(r, n.b >> 24, n.f[0], n.f[1], n.f[2], n.f[3], n.f[4]);
+          const RayF q = to_object_frame<true, true>(r, n.b >> 24, n.f[0], n.f[1], n.f[2], n.f[3], n.f[4]);
           if (STATS) cnt.instance_ops += on;
           if (kind == K_OBJ_LIST) {
             if (n.b & LIST_IS_BOX6) box6_test<STATS>(S.scan, i, n.a, on, q, t_min, t_max, best, cnt);
@@ -486,7 +521,7 @@ __device__ __forceinline__ void scan_range(const DevScene& S, int begin, int end
     else if (MEDIA && kind == K_MEDIUM && LEVEL == 0) {
       // ConstantMedium::hit, hitable.rs:560-598 (commented out in the reference).
       if (__ballot(on) != 0ull) {
-        const RayF q = to_object_frame<true>(r, n.b >> 24, n.f[0], n.f[1], n.f[2], n.f[3], n.f[4]);
+        const RayF q = to_object_frame<true, true>(r, n.b >> 24, n.f[0], n.f[1], n.f[2], n.f[3], n.f[4]);
         const bool box6 = (n.b & LIST_IS_BOX6) != 0;
         const ScanNode ext = load_node(S.scan, n.skip - 1);  // density, ordinal, DevPrim index
         Hit b1, b2;
@@ -1320,6 +1355,9 @@ int validate_scene(const rt_scene* s) {
     if (type < RT_PRIM_SPHERE || type > RT_PRIM_YZ_RECT) return rt::set_error(RT_ERR_INVALID, "unknown primitive type");
     if ((p.type & ~(RT_PRIM_TYPE_MASK | RT_PRIM_FLIP)) != 0) return rt::set_error(RT_ERR_INVALID, "unknown primitive flag");
     if (p.material < 0 || p.material >= s->n_materials) return rt::set_error(RT_ERR_INVALID, "primitive material index out of range");
+    // the kernels' range test takes ordered bounds; a rect built the other way round can never be hit anyway
+    if (type != RT_PRIM_SPHERE && (p.f[0] > p.f[1] || p.f[2] > p.f[3]))
+      return rt::set_error(RT_ERR_UNSUPPORTED, "rect with a lower bound above its upper bound");
   }
   for (int i = 0; i < s->n_objects; ++i) {
     const rt_object& o = s->objects[i];
@@ -1572,6 +1610,7 @@ int check_params(const rt_render_params* p) {
   if (p->nx <= 0 || p->ny <= 0 || p->nx > 32768 || p->ny > 32768) return rt::set_error(RT_ERR_INVALID, "image size out of range");
   if (p->spp <= 0 || p->spp > (1 << 24) || p->sample_begin < 0) return rt::set_error(RT_ERR_INVALID, "spp out of range (1 .. 2^24)");
   if (p->max_depth < 0 || p->max_depth > 1000) return rt::set_error(RT_ERR_INVALID, "max_depth out of range");
+  if (!(p->t_min >= 0.0f) || !(p->t_min < 3.0e38f)) return rt::set_error(RT_ERR_INVALID, "t_min must be finite and not negative");
   if (p->sky != RT_SKY_BLACK && p->sky != RT_SKY_GRADIENT) return rt::set_error(RT_ERR_INVALID, "unknown sky mode");
   if (p->shard_count < 1 || p->shard_index < 0 || p->shard_index >= p->shard_count) return rt::set_error(RT_ERR_INVALID, "bad shard_index/shard_count");
   return RT_OK;
@@ -1859,6 +1898,13 @@ int rt_trace_closest(rt_ctx* ctx, const float* o, const float* d, size_t n, floa
   if (!ctx || !o || !d || !prim_id || !t) return rt::set_error(RT_ERR_INVALID, "rt_trace_closest: null argument");
   if (!ctx->has_scene) return rt::set_error(RT_ERR_NO_SCENE, "rt_trace_closest: no scene uploaded");
   if (n == 0) return RT_OK;
+  if (!(t_min <= t_max)) {
+    // an empty (or NaN) interval: every test rejects (hitable.rs:165), and the kernels assume t_min <= t_max
+    for (size_t i = 0; i < n; ++i) { prim_id[i] = -1; t[i] = 0.0f; }
+    if (normal) std::memset(normal, 0, n * 3 * sizeof(float));
+    if (p) std::memset(p, 0, n * 3 * sizeof(float));
+    return RT_OK;
+  }
   HIP_TRY(hipSetDevice(ctx->device));
   float *d_o = nullptr, *d_d = nullptr, *d_t = nullptr, *d_n = nullptr, *d_p = nullptr;
   int* d_id = nullptr;

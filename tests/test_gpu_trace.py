@@ -101,6 +101,10 @@ def test_trace_finite_interval_and_empty_batch(gpu, orc, cornell):
         assert np.all((t[prim >= 0] >= np.float32(t_min)) & (t[prim >= 0] <= np.float32(t_max)))
     prim, t = gpu.trace_closest(np.zeros((0, 3), np.float32), np.zeros((0, 3), np.float32))
     assert prim.shape == (0,) and t.shape == (0,)
+    # an empty interval rejects everything (hitable.rs:165 with t0 > t1)
+    prim, t = gpu.trace_closest(o, d, t_min=5.0, t_max=1.0)
+    oprim, ot = orc.trace_closest(cornell.flat, o, d, mode=orc.ORC_F32_FUSED, t_min=5.0, t_max=1.0)
+    assert np.all(prim == -1) and np.array_equal(prim, oprim)
     # a ragged size (not a multiple of the wave or block size)
     prim, t = gpu.trace_closest(o[:1001], d[:1001])
     oprim, ot = orc.trace_closest(cornell.flat, o[:1001], d[:1001], mode=orc.ORC_F32_FUSED)
@@ -160,4 +164,14 @@ def test_upload_rejects_malformed_scenes(gpu, cornell):
     nodes[0].left = 0  # a cycle
     with pytest.raises(RtError):
         gpu.upload_scene(bad)
+    # a rect whose bounds are the wrong way round is refused, not mis-rendered
+    prims = (_lib.rt_prim * flat.n_prims)(*[flat.prims[i] for i in range(flat.n_prims)])
+    worse = _lib.rt_scene()
+    for name, _ in _lib.rt_scene._fields_:
+        setattr(worse, name, getattr(flat, name))
+    worse.prims = C.cast(prims, C.POINTER(_lib.rt_prim))
+    prims[0].f[0], prims[0].f[1] = prims[0].f[1] + 1.0, prims[0].f[0]
+    with pytest.raises(RtError) as e:
+        gpu.upload_scene(worse)
+    assert e.value.code == _lib.RT_ERR_UNSUPPORTED
     gpu.upload_scene(flat)
