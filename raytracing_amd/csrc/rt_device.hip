@@ -1066,10 +1066,14 @@ __global__ void __launch_bounds__(64, (GENERAL || TRAV == TRAV_STACK) ? 4 : RT_R
     const bool scatters = hit & (mat_type == RT_MAT_LAMBERTIAN) & (depth < A.max_depth);
     if (STATS) cnt.shade_events += scatters;
     const float xi1 = u01(w.z), xi2 = u01(w.w);
-    // onb.rs:10-21
-    const F3 ww = unit3(sf.normal);
-    const F3 a = fabsf(ww.x) > 0.9f ? f3(0, 1, 0) : f3(1, 0, 0);
-    const F3 vv = unit3(cross3(ww, a));
+    // onb.rs:10-21.  The normal is already of unit length (to rounding), and the cross
+    // product with an axis vector is written out: w x (0,1,0) = (-w.z, 0, w.x),
+    // w x (1,0,0) = (0, w.z, -w.y).
+    const F3 ww = sf.normal;
+    const bool big_x = fabsf(ww.x) > 0.9f;
+    const float other = big_x ? ww.x : ww.y;
+    const float inv_v = fast_rsq(fmaf(ww.z, ww.z, other * other));
+    const F3 vv = f3(big_x ? -ww.z * inv_v : 0.0f, big_x ? 0.0f : ww.z * inv_v, big_x ? ww.x * inv_v : -ww.y * inv_v);
     const F3 uu = cross3(ww, vv);
     const bool pick_light = (S.n_lights > 0) & ((w.y >> 31) != 0u);  // MixturePDF's coin, pdf.rs:70
     // XZRect::random, hitable.rs:256-264
@@ -1180,9 +1184,11 @@ __global__ void __launch_bounds__(64, (GENERAL || TRAV == TRAV_STACK) ? 4 : RT_R
         }
       }
     }
-    ro = sel3(go_on, sf.p, ro);
+    // A lane whose path ended gets a new origin and weight with its next path, so only
+    // the direction is kept clean (it feeds the reciprocals' range test meanwhile).
+    ro = sf.p;
     rd = sel3(go_on, dir, rd);
-    thr = sel3(go_on, thr_next, thr);
+    thr = thr_next;
     depth += go_on ? 1 : 0;
     alive = go_on;
   }
