@@ -861,7 +861,7 @@ struct RenderArgs {
 
 // Waves per SIMD the register allocator must leave room for (launch_bounds' second argument).
 #ifndef RT_RENDER_WAVES_PER_SIMD
-#define RT_RENDER_WAVES_PER_SIMD 6
+#define RT_RENDER_WAVES_PER_SIMD 7
 #endif
 
 #define RT_INV_PI_F 0.31830988618379067154f
