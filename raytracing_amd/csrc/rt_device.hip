@@ -113,6 +113,7 @@ struct DevScene {
   const struct BNode* bnodes;
   const rt_object* objects;
   int stack_mode;
+  int stack_depth;  // entries per lane of the traversal stack
   rt_light light;
 };
 
@@ -127,7 +128,7 @@ struct BNode {
   int right;
 };
 #define BN_INDEX_MASK 0x1fffffff
-#define STACK_DEPTH 32
+#define STACK_DEPTH 64  // deepest tree the stack traversal takes; the launch sizes the LDS stack to the scene's own depth
 #define STACK_RESTORE 0xffffffffu
 
 struct DevCamera {
@@ -736,8 +737,8 @@ template <int TRAV>
 __global__ void __launch_bounds__(256) trace_kernel(DevScene S, const float* __restrict__ o, const float* __restrict__ d, size_t n,
                                                     float t_min, float t_max, int* __restrict__ prim_id, float* __restrict__ t_out,
                                                     float* __restrict__ normal, float* __restrict__ p_out) {
-  __shared__ unsigned stack_lds[TRAV == TRAV_STACK ? 4 * STACK_DEPTH * 64 : 64];
-  unsigned* stk = stack_lds + (TRAV == TRAV_STACK ? (threadIdx.x >> 6) * STACK_DEPTH * 64 : 0) + (threadIdx.x & 63);
+  extern __shared__ unsigned trace_stack_lds[];  // TRAV_STACK: stack_depth entries of 64 lanes for each of the 4 waves
+  unsigned* stk = trace_stack_lds + (TRAV == TRAV_STACK ? (threadIdx.x >> 6) * S.stack_depth * 64 : 0) + (threadIdx.x & 63);
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   // Whole waves stay in the loop together: the traversal uses wave-wide operations.
   const size_t n_round = (n + 63) / 64 * 64;
@@ -792,7 +793,7 @@ __device__ __forceinline__ unsigned perlin_cell(float f) {
 }
 
 // Perlin::noise (perlin.rs:29-50) with perlin_interpolate (perlin.rs:102-124).
-__device__ float perlin_noise(const rt_perlin* __restrict__ pn, F3 p) {
+__device__ __forceinline__ float perlin_noise(const rt_perlin* __restrict__ pn, F3 p) {
   const float fx = floorf(p.x), fy = floorf(p.y), fz = floorf(p.z);
   const float u = p.x - fx, v = p.y - fy, w = p.z - fz;
   const unsigned i = perlin_cell(fx), j = perlin_cell(fy), k = perlin_cell(fz);
@@ -815,7 +816,7 @@ __device__ float perlin_noise(const rt_perlin* __restrict__ pn, F3 p) {
 }
 
 // Perlin::turb (perlin.rs:52-63).
-__device__ float perlin_turb(const rt_perlin* __restrict__ pn, F3 p, int depth) {
+__device__ __noinline__ float perlin_turb(const rt_perlin* __restrict__ pn, F3 p, int depth) {
   float accum = 0.0f, weight = 1.0f;
   for (int o = 0; o < depth; ++o) {
     accum += weight * perlin_noise(pn, p);
@@ -827,16 +828,16 @@ __device__ float perlin_turb(const rt_perlin* __restrict__ pn, F3 p, int depth) 
 
 // Texture::value (texture.rs:22-35).  A checker of checkers is followed down
 // (the source recurses); eight levels are more than any scene here nests.
-__device__ F3 texture_value(const DevScene& S, int tex, F3 p) {
+__device__ __forceinline__ F3 texture_value(const rt_texture* __restrict__ textures, const rt_perlin* __restrict__ perlins, int tex, F3 p) {
   for (int level = 0; level < 8; ++level) {
-    const rt_texture t = S.textures[tex];
+    const rt_texture t = textures[tex];
     if (t.type == RT_TEX_CHECKER) {
       const float sines = fast_sin(10.0f * p.x) * fast_sin(10.0f * p.y) * fast_sin(10.0f * p.z);
       tex = sines < 0.0f ? t.odd : t.even;
       continue;
     }
     if (t.type == RT_TEX_NOISE) {
-      const float g = 0.5f * (1.0f + fast_sin(t.scale * p.z + 10.0f * perlin_turb(S.perlins + t.perlin, p, 7)));
+      const float g = 0.5f * (1.0f + fast_sin(t.scale * p.z + 10.0f * perlin_turb(perlins + t.perlin, p, 7)));
       return f3(g, g, g);
     }
     return f3(t.color[0], t.color[1], t.color[2]);
@@ -869,20 +870,20 @@ struct RenderArgs {
 // ---------------------------------------------------------------------------
 // render_kernel
 // ---------------------------------------------------------------------------
-// GENERAL = false is the build for scenes made of Lambertian and DiffuseLight
-// surfaces with constant textures and no media (the Cornell box); true adds
-// Metal, Dielectric, Isotropic, checker/noise textures and ConstantMedium.
-template <bool STATS, bool SUMSQ, int TRAV, bool GENERAL>
-__global__ void __launch_bounds__(64, (GENERAL || TRAV == TRAV_STACK) ? 4 : RT_RENDER_WAVES_PER_SIMD) render_kernel(DevScene S, DevCamera cam, RenderArgs A, float* __restrict__ out_sum,
+// GENERAL = 0 is the build for scenes made of Lambertian and DiffuseLight
+// surfaces with constant textures and no media (the Cornell box); 1 adds Metal,
+// Dielectric, Isotropic and ConstantMedium; 2 adds checker and noise textures.
+template <bool STATS, bool SUMSQ, int TRAV, int GENERAL>
+__global__ void __launch_bounds__(64, GENERAL == 2 ? 4 : ((GENERAL == 1 || TRAV == TRAV_STACK) ? 5 : RT_RENDER_WAVES_PER_SIMD)) render_kernel(DevScene S, DevCamera cam, RenderArgs A, float* __restrict__ out_sum,
                                                      float* __restrict__ out_sumsq, unsigned long long* __restrict__ stats) {
   // One single-wave workgroup per work item, so a finished wave frees its slot at
   // once instead of waiting for the slowest wave of a larger group.
   __shared__ float acc[1][6][64];
-  __shared__ unsigned stack_lds[TRAV == TRAV_STACK ? STACK_DEPTH * 64 : 64];
   // A flat scene's primitive tables live in LDS (4 + 2 float4 per primitive, the
   // launch sizes the array): a path vertex then costs no global memory access.
   extern __shared__ float4 prim_lds[];
-  unsigned* stk = stack_lds + (threadIdx.x & 63);
+  // The same launch-sized array is the traversal stack of a large scene: stack_depth entries of 64 lanes.
+  unsigned* stk = (unsigned*)prim_lds + (threadIdx.x & 63);
   const int lane = threadIdx.x & 63;
   // The camera (19 floats, used once per path) lives in LDS rather than in scalar
   // registers for the life of the kernel; every lane reads the same address.
@@ -1026,7 +1027,7 @@ __global__ void __launch_bounds__(64, (GENERAL || TRAV == TRAV_STACK) ? 4 : RT_R
     // ---- world.hit(r, 0.001, INFINITY), main.rs:166 ----
     if (STATS) cnt.rays += alive;
     const PathRng rng = {pixel_id, sample, (unsigned)depth, key0, key1};
-    const Hit h = trace_scan<STATS, TRAV, GENERAL>(S, stk, box_tab, alive, ray, A.t_min, INFINITY, rng, cnt);
+    const Hit h = trace_scan<STATS, TRAV, GENERAL != 0>(S, stk, box_tab, alive, ray, A.t_min, INFINITY, rng, cnt);
 
     // ---- color(), main.rs:165-209, one vertex; every lane runs it, dead lanes and
     // misses on primitive 0 with their results masked ----
@@ -1044,9 +1045,9 @@ __global__ void __launch_bounds__(64, (GENERAL || TRAV == TRAV_STACK) ? 4 : RT_R
     const int mat_type = (q.flags >> DP_MAT_SHIFT) & 7;
     F3 color = f3(q.color[0], q.color[1], q.color[2]);
     if (STATS) cnt.hits += hit;
-    if (GENERAL && S.textured) {
+    if (GENERAL == 2 && S.textured) {
       // Texture::value for the lanes whose material has a checker or noise texture.
-      if (hit && (q.flags & DP_TEXTURED)) color = texture_value(S, S.materials[q.flags >> DP_INDEX_SHIFT].texture, sf.p);
+      if (hit && (q.flags & DP_TEXTURED)) color = texture_value(S.textures, S.perlins, S.materials[q.flags >> DP_INDEX_SHIFT].texture, sf.p);
     }
 
     // material.rs:197-203: a light emits towards the side its normal points to and never scatters.
@@ -1284,7 +1285,7 @@ __global__ void tonemap_kernel(const float* __restrict__ sum, size_t n, float sp
 struct rt_ctx {
   int device;
   bool has_scene;
-  bool general;  // the scene needs the GENERAL build of the render kernel
+  int general;  // build of the render kernel the scene needs: 0 Lambertian and lights only, 1 every material and media, 2 also textures
   DevScene dev;
   void* d_scan;
   void* d_prims;
@@ -1678,14 +1679,16 @@ int launch_render(rt_ctx* ctx, const rt_camera* cam, const rt_render_params* p, 
   const int n_items = n_tiles * A.n_chunks;
   const dim3 grid(n_items), block(64);
   typedef void (*RenderFn)(DevScene, DevCamera, RenderArgs, float*, float*, unsigned long long*);
-#define RT_ROW(ST, SQ)                                                                                                      \
-  render_kernel<ST, SQ, TRAV_SCAN, false>, render_kernel<ST, SQ, TRAV_SCAN, true>, render_kernel<ST, SQ, TRAV_FLAT, false>, \
-      render_kernel<ST, SQ, TRAV_FLAT, true>, render_kernel<ST, SQ, TRAV_STACK, false>, render_kernel<ST, SQ, TRAV_STACK, true>
-  static const RenderFn table[24] = {RT_ROW(false, false), RT_ROW(false, true), RT_ROW(true, false), RT_ROW(true, true)};
+#define RT_TRIO(ST, SQ, TR) render_kernel<ST, SQ, TR, 0>, render_kernel<ST, SQ, TR, 1>, render_kernel<ST, SQ, TR, 2>
+#define RT_ROW(ST, SQ) RT_TRIO(ST, SQ, TRAV_SCAN), RT_TRIO(ST, SQ, TRAV_FLAT), RT_TRIO(ST, SQ, TRAV_STACK)
+  static const RenderFn table[36] = {RT_ROW(false, false), RT_ROW(false, true), RT_ROW(true, false), RT_ROW(true, true)};
 #undef RT_ROW
+#undef RT_TRIO
   const int trav = ctx->dev.stack_mode ? TRAV_STACK : (ctx->dev.flat ? TRAV_FLAT : TRAV_SCAN);
-  const RenderFn fn = table[(stats ? 12 : 0) + (d_sumsq ? 6 : 0) + trav * 2 + (ctx->general ? 1 : 0)];
-  const size_t lds_bytes = trav == TRAV_FLAT ? ((size_t)ctx->dev.n_dprims * 4 + (size_t)ctx->dev.n_prims * 2) * sizeof(float4) : 0;
+  const RenderFn fn = table[(stats ? 18 : 0) + (d_sumsq ? 9 : 0) + trav * 3 + ctx->general];
+  size_t lds_bytes = trav == TRAV_FLAT ? ((size_t)ctx->dev.n_dprims * 4 + (size_t)ctx->dev.n_prims * 2) * sizeof(float4) : 0;
+  if (trav == TRAV_STACK) lds_bytes = (size_t)ctx->dev.stack_depth * 64 * sizeof(unsigned);
+  if (const char* pad = std::getenv("RT_DEBUG_LDS_PAD")) lds_bytes += (size_t)std::atoi(pad);  // tuning: caps waves per CU
   hipLaunchKernelGGL(fn, grid, block, lds_bytes, stream, ctx->dev, dc, A, k_sum, k_sumsq, ctx->d_stats);
   HIP_TRY(hipGetLastError());
   if (A.n_chunks > 1) {
@@ -1752,7 +1755,8 @@ int rt_upload_scene(rt_ctx* ctx, const rt_scene* s) {
   if (rc != RT_OK) return rc;
   // More than a treelet's worth of leaves: per-lane stack traversal over the
   // breadth-first nodes; the scan array then keeps only the ConstantMedium nodes.
-  const bool stack_mode = B.any_interior && tree_depth(s, 0) <= STACK_DEPTH - 2;
+  const int depth = tree_depth(s, 0);
+  const bool stack_mode = B.any_interior && depth <= STACK_DEPTH - 2;
   std::vector<BNode> bnodes;
   std::vector<ScanNode> media_scan;
   if (stack_mode) {
@@ -1831,6 +1835,7 @@ int rt_upload_scene(rt_ctx* ctx, const rt_scene* s) {
   d.bnodes = (const BNode*)ctx->d_bnodes;
   d.objects = (const rt_object*)ctx->d_objects;
   d.stack_mode = stack_mode ? 1 : 0;
+  d.stack_depth = stack_mode ? depth + 2 : 0;
   d.mat_mask = mat_mask;
   d.textured = textured;
   d.has_spheres = 0;
@@ -1844,7 +1849,7 @@ int rt_upload_scene(rt_ctx* ctx, const rt_scene* s) {
   d.n_dprims = (int)dprims.size();
   d.n_lights = s->n_lights;
   if (s->n_lights > 0) d.light = s->lights[0];
-  ctx->general = textured || !B.media.empty() || (mat_mask & ~((1 << RT_MAT_LAMBERTIAN) | (1 << RT_MAT_DIFFUSE_LIGHT))) != 0;
+  ctx->general = textured ? 2 : ((!B.media.empty() || (mat_mask & ~((1 << RT_MAT_LAMBERTIAN) | (1 << RT_MAT_DIFFUSE_LIGHT))) != 0) ? 1 : 0);
   ctx->has_scene = true;
   return RT_OK;
 }
@@ -1925,7 +1930,7 @@ int rt_trace_closest(rt_ctx* ctx, const float* o, const float* d, size_t n, floa
   if (e == hipSuccess) {
     size_t blocks = (n + 255) / 256;
     if (blocks > 4096) blocks = 4096;
-    if (ctx->dev.stack_mode) hipLaunchKernelGGL(trace_kernel<TRAV_STACK>, dim3((unsigned)blocks), dim3(256), 0, 0, ctx->dev, d_o, d_d, n, t_min, t_max, d_id, d_t, d_n, d_p);
+    if (ctx->dev.stack_mode) hipLaunchKernelGGL(trace_kernel<TRAV_STACK>, dim3((unsigned)blocks), dim3(256), (size_t)ctx->dev.stack_depth * 4 * 64 * sizeof(unsigned), 0, ctx->dev, d_o, d_d, n, t_min, t_max, d_id, d_t, d_n, d_p);
     else if (ctx->dev.flat) hipLaunchKernelGGL(trace_kernel<TRAV_FLAT>, dim3((unsigned)blocks), dim3(256), 0, 0, ctx->dev, d_o, d_d, n, t_min, t_max, d_id, d_t, d_n, d_p);
     else hipLaunchKernelGGL(trace_kernel<TRAV_SCAN>, dim3((unsigned)blocks), dim3(256), 0, 0, ctx->dev, d_o, d_d, n, t_min, t_max, d_id, d_t, d_n, d_p);
     e = hipGetLastError();
