@@ -111,6 +111,7 @@ struct DevScene {
   // nodes with packed leaf information, and the objects their leaves refer to.  In
   // that mode `scan` holds only the ConstantMedium nodes, walked after the tree.
   const struct BNode* bnodes;
+  const struct BNode2* bnodes2;
   const rt_object* objects;
   int stack_mode;
   int stack_depth;  // entries per lane of the traversal stack
@@ -128,6 +129,17 @@ struct BNode {
   int right;
 };
 #define BN_INDEX_MASK 0x1fffffff
+// What the stack traversal fetches at an interior node: the boxes of its two
+// children and where they are, 64 bytes, so each fetch decides two box tests and
+// a leaf's box never costs a fetch of its own.  A child reference is the child's
+// index in the breadth-first array, with BN2_LEAF set when that child is a leaf.
+struct BNode2 {
+  float lmin[3]; int left;
+  float lmax[3]; int right;
+  float rmin[3]; int pad0;
+  float rmax[3]; int pad1;
+};
+#define BN2_LEAF 0x40000000
 #define STACK_DEPTH 64  // deepest tree the stack traversal takes; the launch sizes the LDS stack to the scene's own depth
 #define STACK_RESTORE 0xffffffffu
 
@@ -313,6 +325,21 @@ __device__ __forceinline__ bool slab_box(float x0, float y0, float z0, float x1,
   t0 = (z0 - r.o.z) * r.inv.z; t1 = (z1 - r.o.z) * r.inv.z;
   t_min = fmaxf(sg.z ? t1 : t0, t_min);
   t_max = fminf(sg.z ? t0 : t1, t_max);
+  return !(t_max <= t_min) & !(t_min > best_t);
+}
+// The same test, also handing back where the ray enters the box (meaningful when it does).
+__device__ __forceinline__ bool slab_box_enter(float4 lo, float4 hi, const RayF& r, const Signs& sg, float t_min, float t_max, float best_t,
+                                               float& t_enter) {
+  float t0 = (lo.x - r.o.x) * r.inv.x, t1 = (hi.x - r.o.x) * r.inv.x;
+  t_min = fmaxf(sg.x ? t1 : t0, t_min);
+  t_max = fminf(sg.x ? t0 : t1, t_max);
+  t0 = (lo.y - r.o.y) * r.inv.y; t1 = (hi.y - r.o.y) * r.inv.y;
+  t_min = fmaxf(sg.y ? t1 : t0, t_min);
+  t_max = fminf(sg.y ? t0 : t1, t_max);
+  t0 = (lo.z - r.o.z) * r.inv.z; t1 = (hi.z - r.o.z) * r.inv.z;
+  t_min = fmaxf(sg.z ? t1 : t0, t_min);
+  t_max = fminf(sg.z ? t0 : t1, t_max);
+  t_enter = t_min;
   return !(t_max <= t_min) & !(t_min > best_t);
 }
 __device__ __forceinline__ bool slab_test(const ScanNode& n, const RayF& r, const Signs& sg, float t_min, float t_max, float best_t) {
@@ -597,13 +624,23 @@ template <bool STATS>
 __device__ __forceinline__ void trace_stack(const DevScene& S, unsigned* __restrict__ stk, const RayF& w, float t_min, float t_max, Hit& best,
                                             Counters& cnt) {
   // stk points at this lane's column; consecutive entries are 64 dwords apart.
+  const int POP = -1;
   int best_rank = -1;
   RayF r = w;
   Signs sg = ray_signs(r);
   int sp = 0;
-  int node = 0;
+  // the root's own box (bvh.rs:198), then the root as a reference
+  int cur;
+  {
+    const float4 lo = *(const float4*)&S.bnodes[0];
+    const float4 hi = *((const float4*)&S.bnodes[0] + 1);
+    float te;
+    if (STATS) cnt.node_tests++;
+    const bool h = slab_box_enter(lo, hi, r, sg, t_min, t_max, best.t, te);
+    cur = h ? (__float_as_int(lo.w) < 0 ? BN2_LEAF : 0) : POP;
+  }
   for (;;) {
-    if (node < 0) {
+    if (cur == POP) {
       if (sp == 0) break;
       --sp;
       const unsigned x = stk[sp * 64];
@@ -612,27 +649,31 @@ __device__ __forceinline__ void trace_stack(const DevScene& S, unsigned* __restr
         sg = ray_signs(r);
         continue;
       }
-      node = (int)x;
+      cur = (int)x;
     }
-    const float4 lo = *(const float4*)&S.bnodes[node];
-    const float4 hi = *((const float4*)&S.bnodes[node] + 1);
-    ScanNode n;  // only the box fields are used by slab_test
-    n.bmin[0] = lo.x; n.bmin[1] = lo.y; n.bmin[2] = lo.z;
-    n.bmax[0] = hi.x; n.bmax[1] = hi.y; n.bmax[2] = hi.z;
-    const int left = __float_as_int(lo.w), right = __float_as_int(hi.w);
-    if (STATS) cnt.node_tests++;
-    node = -1;
-    if (!slab_test(n, r, sg, t_min, t_max, best.t)) continue;
-    if (left >= 0) {
-      const int axis = left >> 29;
-      const bool neg = axis == 0 ? sg.x : (axis == 1 ? sg.y : sg.z);
-      const bool left_far = (((right >> 29) & 1) != 0) != neg;
-      const int l = left & BN_INDEX_MASK, rr = right & BN_INDEX_MASK;
-      stk[sp * 64] = (unsigned)(left_far ? l : rr);
-      ++sp;
-      node = left_far ? rr : l;
+    if (!(cur & BN2_LEAF)) {
+      // interior: both children's boxes from one 64-byte record
+      const float4* rec = (const float4*)&S.bnodes2[cur];
+      const float4 llo = rec[0], lhi = rec[1], rlo = rec[2], rhi = rec[3];
+      float tl, tr;
+      const bool hl = slab_box_enter(llo, lhi, r, sg, t_min, t_max, best.t, tl);
+      const bool hr = slab_box_enter(rlo, rhi, r, sg, t_min, t_max, best.t, tr);
+      if (STATS) cnt.node_tests += 2;
+      const int left = __float_as_int(llo.w), right = __float_as_int(lhi.w);
+      const bool left_first = !(tr < tl);
+      if (hl & hr) {
+        stk[sp * 64] = (unsigned)(left_first ? right : left);
+        ++sp;
+        cur = left_first ? left : right;
+      } else {
+        cur = hl ? left : (hr ? right : POP);
+      }
       continue;
     }
+    // a leaf whose box the ray has passed
+    const int node = cur & BN_INDEX_MASK;
+    cur = POP;
+    const int left = S.bnodes[node].left, right = S.bnodes[node].right;
     const int ref = ~left;
     const int count = right & 0xff, rank = right >> 8;
     if (count > 0) {
@@ -646,11 +687,17 @@ __device__ __forceinline__ void trace_stack(const DevScene& S, unsigned* __restr
     if (ob.kind == RT_OBJ_LIST) {
       prim_list_lane<STATS>(S, ob.first, ob.count, rank, q, t_min, t_max, best, best_rank, cnt);
     } else {
+      // a BvhNode under Translate/RotateY: its root box in the object's frame, then down
       stk[sp * 64] = STACK_RESTORE;
       ++sp;
       r = q;
       sg = ray_signs(r);
-      node = ob.first;
+      const float4 lo = *(const float4*)&S.bnodes[ob.first];
+      const float4 hi = *((const float4*)&S.bnodes[ob.first] + 1);
+      float te;
+      if (STATS) cnt.node_tests++;
+      const bool h = slab_box_enter(lo, hi, r, sg, t_min, t_max, best.t, te);
+      cur = h ? (ob.first | (__float_as_int(lo.w) < 0 ? BN2_LEAF : 0)) : POP;
     }
   }
 }
@@ -1292,6 +1339,7 @@ struct rt_ctx {
   void* d_dprims;
   void* d_leaf_box;
   void* d_bnodes;
+  void* d_bnodes2;
   void* d_objects;
   void* d_materials;
   void* d_textures;
@@ -1315,7 +1363,7 @@ int hip_fail(hipError_t e, const char* what) {
   } while (0)
 
 void free_scene(rt_ctx* ctx) {
-  void** ptrs[] = {&ctx->d_scan, &ctx->d_prims, &ctx->d_dprims, &ctx->d_leaf_box, &ctx->d_bnodes, &ctx->d_objects, &ctx->d_materials, &ctx->d_textures, &ctx->d_perlins};
+  void** ptrs[] = {&ctx->d_scan, &ctx->d_prims, &ctx->d_dprims, &ctx->d_leaf_box, &ctx->d_bnodes, &ctx->d_bnodes2, &ctx->d_objects, &ctx->d_materials, &ctx->d_textures, &ctx->d_perlins};
   for (size_t i = 0; i < sizeof(ptrs) / sizeof(ptrs[0]); ++i) {
     if (*ptrs[i]) (void)hipFree(*ptrs[i]);
     *ptrs[i] = nullptr;
@@ -1820,6 +1868,23 @@ int rt_upload_scene(rt_ctx* ctx, const rt_scene* s) {
   if ((rc = upload(&ctx->d_dprims, dprims.data(), dprims.size())) != RT_OK) return rc;
   if ((rc = upload(&ctx->d_leaf_box, B.leaf_box.data(), B.leaf_box.size())) != RT_OK) return rc;
   if ((rc = upload(&ctx->d_bnodes, bnodes.data(), bnodes.size())) != RT_OK) return rc;
+  // the child-box records of the interior nodes (same index space; leaf entries stay zero)
+  std::vector<BNode2> bnodes2;
+  if (stack_mode) {
+    bnodes2.assign((size_t)s->n_nodes, BNode2());
+    std::memset(bnodes2.data(), 0, bnodes2.size() * sizeof(BNode2));
+    for (int i = 0; i < s->n_nodes; ++i) {
+      const rt_node& n = s->nodes[i];
+      if (n.left < 0) continue;
+      const rt_node& l = s->nodes[n.left];
+      const rt_node& r = s->nodes[n.right];
+      BNode2& b = bnodes2[(size_t)i];
+      for (int c = 0; c < 3; ++c) { b.lmin[c] = l.bmin[c]; b.lmax[c] = l.bmax[c]; b.rmin[c] = r.bmin[c]; b.rmax[c] = r.bmax[c]; }
+      b.left = n.left | (l.left < 0 ? BN2_LEAF : 0);
+      b.right = n.right | (r.left < 0 ? BN2_LEAF : 0);
+    }
+  }
+  if ((rc = upload(&ctx->d_bnodes2, bnodes2.data(), bnodes2.size())) != RT_OK) return rc;
   if ((rc = upload(&ctx->d_objects, s->objects, (size_t)s->n_objects)) != RT_OK) return rc;
   if ((rc = upload(&ctx->d_materials, s->materials, (size_t)s->n_materials)) != RT_OK) return rc;
   if ((rc = upload(&ctx->d_textures, s->textures, (size_t)s->n_textures)) != RT_OK) return rc;
@@ -1833,6 +1898,7 @@ int rt_upload_scene(rt_ctx* ctx, const rt_scene* s) {
   // flat: leaves only, and few enough primitives for the render kernel's LDS tables
   d.flat = (!B.any_interior && !stack_mode && dprims.size() <= (size_t)kFlatMaxPrims) ? 1 : 0;
   d.bnodes = (const BNode*)ctx->d_bnodes;
+  d.bnodes2 = (const BNode2*)ctx->d_bnodes2;
   d.objects = (const rt_object*)ctx->d_objects;
   d.stack_mode = stack_mode ? 1 : 0;
   d.stack_depth = stack_mode ? depth + 2 : 0;
