@@ -112,16 +112,16 @@ struct DevScene {
   // that mode `scan` holds only the ConstantMedium nodes, walked after the tree.
   const struct BNode* bnodes;
   const struct BNode2* bnodes2;
+  const int* prim_rank;  // per primitive: depth-first rank of its leaf
   const rt_object* objects;
   int stack_mode;
   int stack_depth;  // entries per lane of the traversal stack
   rt_light light;
 };
 
-// Breadth-first node for the per-lane stack traversal, 32 bytes (two 16-byte loads).
-//   interior: left  = left child  | split axis << 29
-//             right = right child | (left child is the far one for a positive direction) << 29
-//   leaf:     left  = ~ref (negative); right = count | depth-first leaf rank << 8, count 0 = objects[ref]
+// The breadth-first node array as the stack traversal keeps it, 32 bytes per node:
+// the box (read for the root and for the root of an object's sub-tree) and, for a
+// leaf, left = ~ref (negative) and right = primitive count, 0 meaning objects[ref].
 struct BNode {
   float bmin[3];
   int left;
@@ -132,7 +132,8 @@ struct BNode {
 // What the stack traversal fetches at an interior node: the boxes of its two
 // children and where they are, 64 bytes, so each fetch decides two box tests and
 // a leaf's box never costs a fetch of its own.  A child reference is the child's
-// index in the breadth-first array, with BN2_LEAF set when that child is a leaf.
+// index in the breadth-first array, with BN2_LEAF set when that child is a leaf;
+// a leaf of one primitive is referred to by the primitive's index instead.
 struct BNode2 {
   float lmin[3]; int left;
   float lmax[3]; int right;
@@ -140,6 +141,7 @@ struct BNode2 {
   float rmax[3]; int pad1;
 };
 #define BN2_LEAF 0x40000000
+#define BN2_PRIM 0x20000000  // with BN2_LEAF: a single-primitive leaf, the low bits are the primitive's index
 #define STACK_DEPTH 64  // deepest tree the stack traversal takes; the launch sizes the LDS stack to the scene's own depth
 #define STACK_RESTORE 0xffffffffu
 
@@ -590,8 +592,8 @@ __device__ __forceinline__ void scan_range(const DevScene& S, int begin, int end
 // marker, switches the lane to the object's frame and descends; the marker
 // switches it back.
 template <bool STATS>
-__device__ __forceinline__ void prim_list_lane(const DevScene& S, int first, int count, int rank, const RayF& r, float t_min, float t_max,
-                                               Hit& best, int& best_rank, Counters& cnt) {
+__device__ __forceinline__ void prim_list_lane(const DevScene& S, int first, int count, const RayF& r, float t_min, float t_max, Hit& best,
+                                               Counters& cnt) {
   float loc_t = t_max;
   int loc_prim = -1;
   for (int qi = first; qi < first + count; ++qi) {
@@ -613,10 +615,13 @@ __device__ __forceinline__ void prim_list_lane(const DevScene& S, int first, int
       loc_prim = qi;
     }
   }
-  if (loc_prim >= 0 && (loc_t < best.t || (!(best.t < loc_t) && rank > best_rank))) {
+  if (loc_prim < 0) return;
+  bool take = loc_t < best.t;
+  // an exact tie goes to the leaf that comes later in depth-first order; the ranks are only read then
+  if (!take && !(best.t < loc_t)) take = best.prim < 0 || S.prim_rank[loc_prim] > S.prim_rank[best.prim];
+  if (take) {
     best.t = loc_t;
     best.prim = loc_prim;
-    best_rank = rank;
   }
 }
 
@@ -625,7 +630,6 @@ __device__ __forceinline__ void trace_stack(const DevScene& S, unsigned* __restr
                                             Counters& cnt) {
   // stk points at this lane's column; consecutive entries are 64 dwords apart.
   const int POP = -1;
-  int best_rank = -1;
   RayF r = w;
   Signs sg = ray_signs(r);
   int sp = 0;
@@ -637,7 +641,7 @@ __device__ __forceinline__ void trace_stack(const DevScene& S, unsigned* __restr
     float te;
     if (STATS) cnt.node_tests++;
     const bool h = slab_box_enter(lo, hi, r, sg, t_min, t_max, best.t, te);
-    cur = h ? (__float_as_int(lo.w) < 0 ? BN2_LEAF : 0) : POP;
+    cur = h ? (S.bnodes[0].left < 0 ? BN2_LEAF : 0) : POP;
   }
   for (;;) {
     if (cur == POP) {
@@ -672,12 +676,15 @@ __device__ __forceinline__ void trace_stack(const DevScene& S, unsigned* __restr
     }
     // a leaf whose box the ray has passed
     const int node = cur & BN_INDEX_MASK;
+    const bool single = (cur & BN2_PRIM) != 0;
     cur = POP;
-    const int left = S.bnodes[node].left, right = S.bnodes[node].right;
-    const int ref = ~left;
-    const int count = right & 0xff, rank = right >> 8;
+    if (single) {
+      prim_list_lane<STATS>(S, node, 1, r, t_min, t_max, best, cnt);
+      continue;
+    }
+    const int ref = ~S.bnodes[node].left, count = S.bnodes[node].right;
     if (count > 0) {
-      prim_list_lane<STATS>(S, ref, count, rank, r, t_min, t_max, best, best_rank, cnt);
+      prim_list_lane<STATS>(S, ref, count, r, t_min, t_max, best, cnt);
       continue;
     }
     const rt_object ob = S.objects[ref];
@@ -685,7 +692,7 @@ __device__ __forceinline__ void trace_stack(const DevScene& S, unsigned* __restr
     const RayF q = to_object_frame<true>(w, ob.xform, ob.sin_theta, ob.cos_theta, ob.offset[0], ob.offset[1], ob.offset[2]);
     if (STATS) cnt.instance_ops++;
     if (ob.kind == RT_OBJ_LIST) {
-      prim_list_lane<STATS>(S, ob.first, ob.count, rank, q, t_min, t_max, best, best_rank, cnt);
+      prim_list_lane<STATS>(S, ob.first, ob.count, q, t_min, t_max, best, cnt);
     } else {
       // a BvhNode under Translate/RotateY: its root box in the object's frame, then down
       stk[sp * 64] = STACK_RESTORE;
@@ -697,7 +704,7 @@ __device__ __forceinline__ void trace_stack(const DevScene& S, unsigned* __restr
       float te;
       if (STATS) cnt.node_tests++;
       const bool h = slab_box_enter(lo, hi, r, sg, t_min, t_max, best.t, te);
-      cur = h ? (ob.first | (__float_as_int(lo.w) < 0 ? BN2_LEAF : 0)) : POP;
+      cur = h ? (ob.first | (S.bnodes[ob.first].left < 0 ? BN2_LEAF : 0)) : POP;
     }
   }
 }
@@ -1340,6 +1347,7 @@ struct rt_ctx {
   void* d_leaf_box;
   void* d_bnodes;
   void* d_bnodes2;
+  void* d_prim_rank;
   void* d_objects;
   void* d_materials;
   void* d_textures;
@@ -1363,7 +1371,7 @@ int hip_fail(hipError_t e, const char* what) {
   } while (0)
 
 void free_scene(rt_ctx* ctx) {
-  void** ptrs[] = {&ctx->d_scan, &ctx->d_prims, &ctx->d_dprims, &ctx->d_leaf_box, &ctx->d_bnodes, &ctx->d_bnodes2, &ctx->d_objects, &ctx->d_materials, &ctx->d_textures, &ctx->d_perlins};
+  void** ptrs[] = {&ctx->d_scan, &ctx->d_prims, &ctx->d_dprims, &ctx->d_leaf_box, &ctx->d_bnodes, &ctx->d_bnodes2, &ctx->d_prim_rank, &ctx->d_objects, &ctx->d_materials, &ctx->d_textures, &ctx->d_perlins};
   for (size_t i = 0; i < sizeof(ptrs) / sizeof(ptrs[0]); ++i) {
     if (*ptrs[i]) (void)hipFree(*ptrs[i]);
     *ptrs[i] = nullptr;
@@ -1619,36 +1627,29 @@ int tree_depth(const rt_scene* s, int idx) {
   return 1;
 }
 
-// Fills the stack-traversal copy of the nodes under idx: split axis and child
-// order for interior nodes, primitive count and depth-first rank for leaves.
-int build_bnodes(const rt_scene* s, int idx, std::vector<BNode>* out, int* rank) {
+// Fills the stack traversal's copy of the nodes under idx and gives every
+// primitive the depth-first rank of its leaf (what decides an exact tie).
+int build_bnodes(const rt_scene* s, int idx, std::vector<BNode>* out, std::vector<int>* prim_rank, int* rank) {
   const rt_node& n = s->nodes[idx];
   BNode& b = (*out)[(size_t)idx];
   for (int c = 0; c < 3; ++c) { b.bmin[c] = n.bmin[c]; b.bmax[c] = n.bmax[c]; }
+  b.left = n.left;
+  b.right = n.right;
   if (n.left >= 0) {
     if (n.left > BN_INDEX_MASK || n.right > BN_INDEX_MASK) return rt::set_error(RT_ERR_UNSUPPORTED, "too many nodes");
-    const rt_node& l = s->nodes[n.left];
-    const rt_node& r = s->nodes[n.right];
-    int axis = 0;
-    float best = -1.0f;
-    for (int c = 0; c < 3; ++c) {
-      const float d = std::fabs((l.bmin[c] + l.bmax[c]) - (r.bmin[c] + r.bmax[c]));
-      if (d > best) { best = d; axis = c; }
-    }
-    // for a ray travelling in +axis the child with the larger centre is the far one
-    const bool left_far_pos = (l.bmin[axis] + l.bmax[axis]) > (r.bmin[axis] + r.bmax[axis]);
-    b.left = n.left | (axis << 29);
-    b.right = n.right | ((left_far_pos ? 1 : 0) << 29);
-    int rc = build_bnodes(s, n.left, out, rank);
+    int rc = build_bnodes(s, n.left, out, prim_rank, rank);
     if (rc != RT_OK) return rc;
-    return build_bnodes(s, n.right, out, rank);
+    return build_bnodes(s, n.right, out, prim_rank, rank);
   }
   if (n.right > 255) return rt::set_error(RT_ERR_UNSUPPORTED, "a leaf list longer than 255 primitives");
-  if (*rank >= (1 << 23)) return rt::set_error(RT_ERR_UNSUPPORTED, "too many leaves");
-  b.left = n.left;
-  b.right = n.right | (*rank << 8);
+  const int ref = ~n.left;
+  if (n.right > 0) {
+    for (int k = ref; k < ref + n.right; ++k) (*prim_rank)[(size_t)k] = *rank;
+  } else if (s->objects[ref].kind != RT_OBJ_BVH) {
+    for (int k = s->objects[ref].first; k < s->objects[ref].first + s->objects[ref].count; ++k) (*prim_rank)[(size_t)k] = *rank;
+  }
   ++*rank;
-  if (n.right == 0 && s->objects[~n.left].kind == RT_OBJ_BVH) return build_bnodes(s, s->objects[~n.left].first, out, rank);
+  if (n.right == 0 && s->objects[ref].kind == RT_OBJ_BVH) return build_bnodes(s, s->objects[ref].first, out, prim_rank, rank);
   return RT_OK;
 }
 
@@ -1806,11 +1807,12 @@ int rt_upload_scene(rt_ctx* ctx, const rt_scene* s) {
   const int depth = tree_depth(s, 0);
   const bool stack_mode = B.any_interior && depth <= STACK_DEPTH - 2;
   std::vector<BNode> bnodes;
+  std::vector<int> prim_rank((size_t)s->n_prims, 0);
   std::vector<ScanNode> media_scan;
   if (stack_mode) {
     bnodes.assign((size_t)s->n_nodes, BNode());
     int rank = 0;
-    rc = build_bnodes(s, 0, &bnodes, &rank);
+    rc = build_bnodes(s, 0, &bnodes, &prim_rank, &rank);
     if (rc != RT_OK) return rc;
     for (size_t i = 0; i < B.out.size();) {
       const int slots = B.out[i].kind == K_INTERIOR ? 1 : B.out[i].skip - (int)i;
@@ -1880,11 +1882,16 @@ int rt_upload_scene(rt_ctx* ctx, const rt_scene* s) {
       const rt_node& r = s->nodes[n.right];
       BNode2& b = bnodes2[(size_t)i];
       for (int c = 0; c < 3; ++c) { b.lmin[c] = l.bmin[c]; b.lmax[c] = l.bmax[c]; b.rmin[c] = r.bmin[c]; b.rmax[c] = r.bmax[c]; }
-      b.left = n.left | (l.left < 0 ? BN2_LEAF : 0);
-      b.right = n.right | (r.left < 0 ? BN2_LEAF : 0);
+      auto ref_of = [](int child, const rt_node& c) {
+        if (c.left >= 0) return child;
+        return c.right == 1 ? (BN2_LEAF | BN2_PRIM | ~c.left) : (BN2_LEAF | child);
+      };
+      b.left = ref_of(n.left, l);
+      b.right = ref_of(n.right, r);
     }
   }
   if ((rc = upload(&ctx->d_bnodes2, bnodes2.data(), bnodes2.size())) != RT_OK) return rc;
+  if ((rc = upload(&ctx->d_prim_rank, prim_rank.data(), prim_rank.size())) != RT_OK) return rc;
   if ((rc = upload(&ctx->d_objects, s->objects, (size_t)s->n_objects)) != RT_OK) return rc;
   if ((rc = upload(&ctx->d_materials, s->materials, (size_t)s->n_materials)) != RT_OK) return rc;
   if ((rc = upload(&ctx->d_textures, s->textures, (size_t)s->n_textures)) != RT_OK) return rc;
@@ -1899,6 +1906,7 @@ int rt_upload_scene(rt_ctx* ctx, const rt_scene* s) {
   d.flat = (!B.any_interior && !stack_mode && dprims.size() <= (size_t)kFlatMaxPrims) ? 1 : 0;
   d.bnodes = (const BNode*)ctx->d_bnodes;
   d.bnodes2 = (const BNode2*)ctx->d_bnodes2;
+  d.prim_rank = (const int*)ctx->d_prim_rank;
   d.objects = (const rt_object*)ctx->d_objects;
   d.stack_mode = stack_mode ? 1 : 0;
   d.stack_depth = stack_mode ? depth + 2 : 0;
