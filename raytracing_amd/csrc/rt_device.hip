@@ -1737,7 +1737,6 @@ int launch_render(rt_ctx* ctx, const rt_camera* cam, const rt_render_params* p, 
   const RenderFn fn = table[(stats ? 18 : 0) + (d_sumsq ? 9 : 0) + trav * 3 + ctx->general];
   size_t lds_bytes = trav == TRAV_FLAT ? ((size_t)ctx->dev.n_dprims * 4 + (size_t)ctx->dev.n_prims * 2) * sizeof(float4) : 0;
   if (trav == TRAV_STACK) lds_bytes = (size_t)ctx->dev.stack_depth * 64 * sizeof(unsigned);
-  if (const char* pad = std::getenv("RT_DEBUG_LDS_PAD")) lds_bytes += (size_t)std::atoi(pad);  // tuning: caps waves per CU
   hipLaunchKernelGGL(fn, grid, block, lds_bytes, stream, ctx->dev, dc, A, k_sum, k_sumsq, ctx->d_stats);
   HIP_TRY(hipGetLastError());
   if (A.n_chunks > 1) {
