@@ -215,3 +215,19 @@ def test_device_render_matches_reference_example_png(gpu, cornell, tmp_path):
     assert np.sqrt((diff ** 2).mean()) < 0.5, np.sqrt((diff ** 2).mean())
     assert abs(diff.mean()) < 0.3, diff.mean()
     assert back[:10].max() == 0 and back[:, :10].max() == 0  # the black frame
+
+
+def test_render_large_image_low_spp(gpu, orc, cornell):
+    """3840x2160 at 2 samples per pixel: 129,600 tiles, every index past 2^16,
+    against the oracle on the same random stream."""
+    gpu.upload_scene(cornell.flat)
+    nx, ny, spp = 3840, 2160, 2
+    p = make_params(nx, ny, spp, seed=4)
+    s, stats = gpu.render(cornell.camera, p, want_stats=True)
+    assert stats.paths == nx * ny * spp
+    o, _ = orc.render(cornell.flat, cornell.camera.c, p, mode=orc.ORC_F32_FUSED, n_threads=8)
+    assert np.isclose(s, o, rtol=2e-4, atol=1e-4).mean() > 0.98
+    assert abs(s.sum() - o.sum()) / o.sum() < 2e-3
+    # the corners and the centre are where an indexing slip would show
+    for ys, xs in ((slice(0, 64), slice(0, 64)), (slice(ny - 64, ny), slice(nx - 64, nx)), (slice(1000, 1100), slice(1900, 2000))):
+        assert np.isclose(s[ys, xs], o[ys, xs], rtol=2e-4, atol=1e-4).mean() > 0.97
