@@ -122,7 +122,7 @@ def main():
     image_checksum = float(buf.double().sum().item()) if rank == 0 else 0.0
 
     # HBM bytes per launch of the dominant kernel from a committed PMC profile of this exact workload
-    # (rocprofv3 FETCH_SIZE / WRITE_SIZE passes; tools_profile.sh), null for any other workload
+    # (rocprofv3 FETCH_SIZE / WRITE_SIZE passes; tools/profile.sh), null for any other workload
     traffic = None
     traffic_file = os.path.join(ROOT, "profiles", "r1", "traffic.json")
     if (nx, ny, spp, world) == (1024, 1024, 1000, 1) and os.path.exists(traffic_file):

@@ -352,9 +352,6 @@ __device__ __forceinline__ bool slab_test(const ScanNode& n, const RayF& r, cons
 // axis, A and B the in-plane axes in constructor order; f = a0,a1,b0,b1,k.  The
 // source's rejects are kept as written so a NaN passes them exactly as it does
 // there.  t = (k - o[C]) * (1/d[C]) replaces the source's division.
-#ifndef RT_RECT_MED3
-#define RT_RECT_MED3 1
-#endif
 template <int C, int A, int B>
 __device__ __forceinline__ bool rect_test(const float* f, const RayF& r, float t0, float t1, float& t_out) {
   const float oc = C == 0 ? r.o.x : (C == 1 ? r.o.y : r.o.z);
@@ -367,17 +364,12 @@ __device__ __forceinline__ bool rect_test(const float* f, const RayF& r, float t
   const float a = fmaf(t, da, oa);
   const float b = fmaf(t, db, ob);
   t_out = t;
-#if RT_RECT_MED3
   // x lies in [lo, hi] exactly when the median of the three is x (the bounds are
   // ordered: rt_upload_scene refuses a rect with a0 > a1, the callers keep
   // t0 <= t1).  A NaN x makes the median one of the bounds and the comparison
   // unordered, which counts as inside, as the source's two rejects do.
   const float mt = __builtin_amdgcn_fmed3f(t, t0, t1), ma = __builtin_amdgcn_fmed3f(a, f[0], f[1]), mb = __builtin_amdgcn_fmed3f(b, f[2], f[3]);
   return !((mt < t) | (mt > t)) & !((ma < a) | (ma > a)) & !((mb < b) | (mb > b));
-#else
-  const bool miss = (t < t0) | (t > t1) | (a < f[0]) | (a > f[1]) | (b < f[2]) | (b > f[3]);
-  return !miss;
-#endif
 }
 
 // Sphere::hit (hitable.rs:50-82): half-b quadratic, nearer root first, strict
@@ -713,9 +705,6 @@ __device__ __forceinline__ void trace_stack(const DevScene& S, unsigned* __restr
 // TRAV is chosen by the host per scene: each variant is its own kernel so the
 // register allocator only sees the code that scene can reach.
 enum { TRAV_SCAN = 0, TRAV_FLAT = 1, TRAV_STACK = 2 };
-#ifndef RT_FLAT_DEFER
-#define RT_FLAT_DEFER 1
-#endif
 template <bool STATS, int TRAV, bool MEDIA>
 __device__ __forceinline__ Hit trace_scan(const DevScene& S, unsigned* stk, const float4* leaf_box, bool active, const RayF& w, float t_min,
                                           float t_max, const PathRng& rng, Counters& cnt) {
@@ -726,7 +715,7 @@ __device__ __forceinline__ Hit trace_scan(const DevScene& S, unsigned* stk, cons
     if (active) trace_stack<STATS>(S, stk, w, t_min, t_max, best, cnt);
     // what is left in the scan array in this mode: the ConstantMedium nodes
     if (MEDIA && S.n_scan > 0) scan_range<STATS, true, true, 0>(S, 0, S.n_scan, active, w, t_min, t_max, rng, best, cnt);
-  } else if (TRAV == TRAV_FLAT && !MEDIA && RT_FLAT_DEFER) {
+  } else if (TRAV == TRAV_FLAT && !MEDIA) {
     // A flat array of leaves: the nearest hit is the candidate with the smallest t,
     // the later leaf winning a tie, among those whose leaf box the ray also passes
     // (bvh.rs:198-203).  The box test almost never rejects a candidate whose own

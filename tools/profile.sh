@@ -1,6 +1,6 @@
 #!/bin/bash
 # Profiling recipe for the GPU box (run through gpurun from the repository root):
-#   tools_profile.sh <tag>      writes gpurun_out/prof_<tag>/
+#   tools/profile.sh <tag>      writes gpurun_out/prof_<tag>/
 # 1) kernel trace + stats of the default benchmark command;
 # 2) PMC passes of one launch of the headline workload, one counter set per run;
 # 3) a text summary (per-kernel durations, counters per launch, HBM traffic per launch).
@@ -20,5 +20,5 @@ pass pmc1 SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_ACTIVE_INST_VALU
 pass pmc2 SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_LDS SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_SALU SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_LDS
 pass pmc3 FETCH_SIZE GRBM_GUI_ACTIVE
 pass pmc4 WRITE_SIZE TCC_HIT_sum TCC_MISS_sum
-python3 $R/tools_profile_summary.py $OUT > $OUT/summary.txt || exit 1
+python3 $R/tools/profile_summary.py $OUT > $OUT/summary.txt || exit 1
 cat $OUT/summary.txt

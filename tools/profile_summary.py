@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Condenses one tools_profile.sh output directory into a text summary:
+"""Condenses one tools/profile.sh output directory into a text summary:
 the bench line of the traced run, rocprofv3's per-kernel statistics, the PMC
 counters of one launch of each kernel and the HBM traffic per launch.
 
