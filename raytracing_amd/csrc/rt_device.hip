@@ -106,7 +106,7 @@ struct DevScene {
   int textured;  // some material needs Texture::value (checker / noise)
   int has_spheres;
   int flat;  // 1: the scan array holds leaves only (every skip is the next index)
-  const float4* leaf_box;  // per primitive: bmin, bmax of the scan leaf that holds it (two float4)
+  const float4* leaf_box;  // per DevPrim: bmin, bmax of the scan leaf that holds it (two float4)
   // Stack traversal (scenes with more than a handful of leaves): the breadth-first
   // nodes with packed leaf information, and the objects their leaves refer to.  In
   // that mode `scan` holds only the ConstantMedium nodes, walked after the tree.
@@ -715,7 +715,7 @@ __device__ __forceinline__ Hit trace_scan(const DevScene& S, unsigned* stk, cons
     if (active) trace_stack<STATS>(S, stk, w, t_min, t_max, best, cnt);
     // what is left in the scan array in this mode: the ConstantMedium nodes
     if (MEDIA && S.n_scan > 0) scan_range<STATS, true, true, 0>(S, 0, S.n_scan, active, w, t_min, t_max, rng, best, cnt);
-  } else if (TRAV == TRAV_FLAT && !MEDIA) {
+  } else if (TRAV == TRAV_FLAT) {
     // A flat array of leaves: the nearest hit is the candidate with the smallest t,
     // the later leaf winning a tie, among those whose leaf box the ray also passes
     // (bvh.rs:198-203).  The box test almost never rejects a candidate whose own
@@ -724,7 +724,7 @@ __device__ __forceinline__ Hit trace_scan(const DevScene& S, unsigned* stk, cons
     // winner among the box-tested candidates, each of which is one of the
     // candidates it beat.  If it fails for any lane, the wave redoes the scan
     // with every box test in place.
-    scan_range<STATS, true, false, 0, true>(S, 0, S.n_scan, active, w, t_min, t_max, rng, best, cnt);
+    scan_range<STATS, true, MEDIA, 0, true>(S, 0, S.n_scan, active, w, t_min, t_max, rng, best, cnt);
     const bool got = active & (best.prim >= 0);
     const float4* lb = leaf_box + 2 * (got ? best.prim : 0);
     const float4 b0 = lb[0], b1 = lb[1];
@@ -733,7 +733,7 @@ __device__ __forceinline__ Hit trace_scan(const DevScene& S, unsigned* stk, cons
     if (__builtin_expect(__ballot(got & !ok) != 0ull, 0)) {
       best.t = t_max;
       best.prim = -1;
-      scan_range<STATS, true, false, 0, false>(S, 0, S.n_scan, active, w, t_min, t_max, rng, best, cnt);
+      scan_range<STATS, true, MEDIA, 0, false>(S, 0, S.n_scan, active, w, t_min, t_max, rng, best, cnt);
     }
   } else {
     scan_range<STATS, TRAV == TRAV_FLAT, MEDIA, 0>(S, 0, S.n_scan, active, w, t_min, t_max, rng, best, cnt);
@@ -948,7 +948,7 @@ __global__ void __launch_bounds__(64, GENERAL == 2 ? 4 : ((GENERAL == 1 || TRAV 
   const float4* box_tab = S.leaf_box;
   if (TRAV == TRAV_FLAT) {
     for (int k = lane; k < S.n_dprims * 4; k += 64) prim_lds[k] = dprim_tab[k];
-    for (int k = lane; k < S.n_prims * 2; k += 64) prim_lds[S.n_dprims * 4 + k] = box_tab[k];
+    for (int k = lane; k < S.n_dprims * 2; k += 64) prim_lds[S.n_dprims * 4 + k] = box_tab[k];
     dprim_tab = prim_lds;
     box_tab = prim_lds + S.n_dprims * 4;
     __syncthreads();
@@ -1578,6 +1578,9 @@ int build_scan(ScanBuilder* B, int idx, bool in_sub, bool collapsed, bool tree_r
     B->out.push_back(sn);
     if (sn.b & LIST_IS_BOX6) push_box6(s, ob.first, &B->out);
     if (medium) {
+      // the medium's own scattering record comes after the primitives; it gets the leaf's box too
+      B->leaf_box.resize(((size_t)s->n_prims + B->media.size() + 1) * 8, 0.0f);
+      B->set_leaf_box(s->n_prims + (int)B->media.size(), n);
       ScanNode ext;
       std::memset(&ext, 0, sizeof(ext));
       ext.f[0] = ob.density;
@@ -1724,7 +1727,7 @@ int launch_render(rt_ctx* ctx, const rt_camera* cam, const rt_render_params* p, 
 #undef RT_TRIO
   const int trav = ctx->dev.stack_mode ? TRAV_STACK : (ctx->dev.flat ? TRAV_FLAT : TRAV_SCAN);
   const RenderFn fn = table[(stats ? 18 : 0) + (d_sumsq ? 9 : 0) + trav * 3 + ctx->general];
-  size_t lds_bytes = trav == TRAV_FLAT ? ((size_t)ctx->dev.n_dprims * 4 + (size_t)ctx->dev.n_prims * 2) * sizeof(float4) : 0;
+  size_t lds_bytes = trav == TRAV_FLAT ? (size_t)ctx->dev.n_dprims * 6 * sizeof(float4) : 0;
   if (trav == TRAV_STACK) lds_bytes = (size_t)ctx->dev.stack_depth * 64 * sizeof(unsigned);
   hipLaunchKernelGGL(fn, grid, block, lds_bytes, stream, ctx->dev, dc, A, k_sum, k_sumsq, ctx->d_stats);
   HIP_TRY(hipGetLastError());
@@ -1856,6 +1859,7 @@ int rt_upload_scene(rt_ctx* ctx, const rt_scene* s) {
     d.ref_idx = m.ref_idx;
   }
   if ((rc = upload(&ctx->d_dprims, dprims.data(), dprims.size())) != RT_OK) return rc;
+  B.leaf_box.resize(dprims.size() * 8, 0.0f);
   if ((rc = upload(&ctx->d_leaf_box, B.leaf_box.data(), B.leaf_box.size())) != RT_OK) return rc;
   if ((rc = upload(&ctx->d_bnodes, bnodes.data(), bnodes.size())) != RT_OK) return rc;
   // the child-box records of the interior nodes (same index space; leaf entries stay zero)
