@@ -46,6 +46,7 @@ def main():
     ap.add_argument("--spp", type=int, default=16)
     ap.add_argument("--spheres", type=int, default=1 << 20)
     ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--lbvh", action="store_true", help="rebuild the world tree on the device (rt_build_lbvh): a separate variant")
     ap.add_argument("--cpu-spp", type=int, default=0, help="also time the f64 oracle at this many spp (8 threads)")
     args = ap.parse_args()
 
@@ -61,6 +62,12 @@ def main():
         flat = sc.flatten(world)
     t_build = time.perf_counter() - t0
     r = Renderer(0)
+    t_lbvh = None
+    if args.lbvh:
+        r.build_lbvh(flat)  # first call pays for library initialisation
+        t1 = time.perf_counter()
+        flat = r.build_lbvh(flat)
+        t_lbvh = time.perf_counter() - t1
     r.upload_scene(flat)
     p = make_params(args.nx, args.ny, args.spp, sky=sky)
     best = None
@@ -84,6 +91,7 @@ def main():
         prod_ms = ms if prod_ms is None else min(prod_ms, ms)
     line = {
         "scene": args.scene, "nx": args.nx, "ny": args.ny, "spp": args.spp, "nodes": flat.n_nodes, "prims": flat.n_prims,
+        "tree": "device LBVH (variant)" if args.lbvh else "reference median split", "lbvh_build_s": None if t_lbvh is None else round(t_lbvh, 4),
         "build_s": round(t_build, 2), "kernel_ms": round(prod_ms, 3), "counting_kernel_ms": round(best.kernel_ms, 3),
         "Mpaths_per_s": round(paths / prod_ms / 1e3, 2), "Mrays_per_s": round(best.rays / prod_ms / 1e3, 2),
         "rays_per_path": round(best.rays / float(paths), 3), "node_tests_per_ray": round(best.node_tests / float(best.rays), 2),

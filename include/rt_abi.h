@@ -267,6 +267,17 @@ int rt_trace_closest(rt_ctx* ctx, const float* o, const float* d, size_t n, floa
 int rt_tonemap(rt_ctx* ctx, const float* sum_rgb, int32_t nx, int32_t ny, int32_t spp_total,
                uint8_t* rgb8);
 
+/* An alternative to BvhNode::new (src/bvh.rs:105-147) for the world tree, built on
+ * the device: a linear BVH (Morton order of the leaf-box centres, hierarchy from the
+ * sorted keys, boxes fitted bottom-up) over the same leaves.  nodes_out receives
+ * scene->n_nodes nodes: the scene's own array with the interior nodes of the world
+ * tree replaced (leaves, their boxes and the sub-trees inside objects are kept, so
+ * every other array of the scene still applies).  Use it by uploading a copy of the
+ * scene whose `nodes` points at nodes_out.  The tree is not the reference's, so box
+ * test counts and the winner of an exact tie differ: a separately reported variant,
+ * never the parity configuration. */
+int rt_build_lbvh(rt_ctx* ctx, const rt_scene* scene, rt_node* nodes_out);
+
 /* Device self-test with no counterpart in the reference: the kernels replace
  * the three divisions 1/d of Aabb::hit (src/bvh.rs:47) by a short reciprocal
  * sequence that must equal the correctly rounded quotient.  This runs the

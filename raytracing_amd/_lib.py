@@ -133,6 +133,7 @@ def lib():
     sig("rt_trace_closest", C.c_int, vp, vp, vp, C.c_size_t, C.c_float, C.c_float, vp, vp, vp, vp)
     sig("rt_tonemap", C.c_int, vp, vp, C.c_int32, C.c_int32, C.c_int32, vp)
     sig("rt_selftest_reciprocal", C.c_int, vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32))
+    sig("rt_build_lbvh", C.c_int, vp, C.POINTER(rt_scene), vp)
 
     sig("rtb_create", C.c_int, C.c_uint64, C.POINTER(vp))
     sig("rtb_destroy", C.c_int, vp)

@@ -1744,6 +1744,8 @@ int launch_render(rt_ctx* ctx, const rt_camera* cam, const rt_render_params* p, 
 
 }  // namespace
 
+int rt::context_device(const rt_ctx* ctx) { return ctx->device; }
+
 extern "C" {
 
 int rt_create(int device_id, rt_ctx** out) {

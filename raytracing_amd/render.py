@@ -85,6 +85,19 @@ class Renderer(object):
         check(_lib.lib().rt_tonemap(self._ctx, a.ctypes.data, nx, ny, spp_total, out.ctypes.data))
         return out
 
+    def build_lbvh(self, flat_scene):
+        """The scene with its world tree rebuilt on the device as a linear BVH
+        (rt_build_lbvh): a copy of `flat_scene` whose node array belongs to the
+        returned object; the other arrays are shared with `flat_scene`."""
+        nodes = (_lib.rt_node * flat_scene.n_nodes)()
+        check(_lib.lib().rt_build_lbvh(self._ctx, C.byref(flat_scene), nodes))
+        out = _lib.rt_scene()
+        for name, _ in _lib.rt_scene._fields_:
+            setattr(out, name, getattr(flat_scene, name))
+        out.nodes = C.cast(nodes, C.POINTER(_lib.rt_node))
+        out._keep = (nodes, flat_scene)  # the arrays must outlive the struct that points at them
+        return out
+
     def selftest_reciprocal(self):
         """Runs the kernels' reciprocal sequence against the correctly rounded
         division for all 2^32 float bit patterns on the device.  Returns

@@ -175,3 +175,100 @@ def test_upload_rejects_malformed_scenes(gpu, cornell):
         gpu.upload_scene(worse)
     assert e.value.code == _lib.RT_ERR_UNSUPPORTED
     gpu.upload_scene(flat)
+
+
+def _lbvh_scene(n_spheres, seed):
+    from raytracing_amd import Scene
+    from raytracing_amd import scene as S
+    rng = np.random.RandomState(seed)
+    sc = Scene(seed)
+    sc.__enter__()
+    mats = [S.Lambertian.new_from_color(S.vec3(*rng.rand(3))) for _ in range(4)]
+    items = [S.Sphere.new(S.vec3(0.0, -1000.0, 0.0), 1000.0, mats[0])]
+    for _ in range(n_spheres):
+        items.append(S.Sphere.new(S.vec3(*rng.uniform(-20, 20, 3)) + S.vec3(0, 21, 0), float(rng.uniform(0.1, 0.8)), mats[rng.randint(4)]))
+    cluster = [S.Sphere.new(S.vec3(*rng.uniform(0, 6, 3)), 0.4, mats[rng.randint(4)]) for _ in range(60)]
+    items.append(S.Translate.new(S.RotateY.new(S.BvhNode.new(cluster), 15.0), S.vec3(-10.0, 3.0, 4.0)))
+    items.append(S.Translate.new(S.RotateY.new(S.Cuboid.new(S.vec3(0, 0, 0), S.vec3(2, 4, 3), mats[1]), -30.0), S.vec3(5.0, 0.0, 5.0)))
+    flat = sc.flatten(S.HitableList.new(items))
+    sc.__exit__(None, None, None)
+    return sc, flat
+
+
+def test_lbvh_world_tree_variant(gpu, orc):
+    """rt_build_lbvh: the device-built tree keeps every leaf, its boxes enclose
+    their children, the traversal of it matches the oracle walking the same tree
+    bit for bit, and its nearest hits are the reference tree's except for exact
+    ties."""
+    sc, flat = _lbvh_scene(3000, 7)
+    lb = gpu.build_lbvh(flat)
+    assert lb.n_nodes == flat.n_nodes
+    n = flat.n_nodes
+    seen = np.zeros(n, dtype=int)
+
+    def walk(i, depth):
+        seen[i] += 1
+        nd = lb.nodes[i]
+        if nd.left < 0:
+            return depth
+        deepest = 0
+        for c in (nd.left, nd.right):
+            ch = lb.nodes[c]
+            for k in range(3):
+                assert nd.bmin[k] <= ch.bmin[k] and nd.bmax[k] >= ch.bmax[k]
+            deepest = max(deepest, walk(c, depth + 1))
+        return deepest
+
+    import sys
+    sys.setrecursionlimit(10000)
+    depth = walk(0, 1)
+    assert depth < 40
+    leaves_old = [(i, flat.nodes[i].left, flat.nodes[i].right) for i in range(n) if flat.nodes[i].left < 0]
+    leaves_new = [(i, lb.nodes[i].left, lb.nodes[i].right) for i in range(n) if lb.nodes[i].left < 0]
+    assert leaves_old == leaves_new
+    # every world node reached exactly once; the nodes of the object's sub-tree are untouched
+    sub = seen == 0
+    assert seen.max() == 1 and sub.sum() == 2 * 60 - 1
+    for i in np.nonzero(sub)[0]:
+        a, b = flat.nodes[int(i)], lb.nodes[int(i)]
+        assert (a.left, a.right, list(a.bmin), list(a.bmax)) == (b.left, b.right, list(b.bmin), list(b.bmax))
+
+    rng = np.random.RandomState(1)
+    m = 50000
+    o = rng.uniform(-25, 25, size=(m, 3)).astype(np.float32)
+    o[:, 1] = np.abs(o[:, 1]) + 0.5
+    tgt = rng.uniform(-20, 20, size=(m, 3)).astype(np.float32)
+    tgt[:, 1] = np.abs(tgt[:, 1])
+    d = (tgt - o).astype(np.float32)
+    gpu.upload_scene(flat)
+    p_ref, t_ref = gpu.trace_closest(o, d)
+    gpu.upload_scene(lb)
+    p_lb, t_lb, nrm, pt = gpu.trace_closest(o, d, want_normal=True, want_p=True)
+    op, ot, on, opt = orc.trace_closest(lb, o, d, mode=orc.ORC_F32_FUSED, want_normal=True, want_p=True)
+    assert np.array_equal(p_lb, op) and np.array_equal(t_lb, ot.astype(np.float32))
+    assert np.array_equal(nrm, on.astype(np.float32)) and np.array_equal(pt, opt.astype(np.float32))
+    same = p_lb == p_ref
+    assert same.mean() > 0.9995, same.mean()
+    assert np.array_equal(t_lb[same], t_ref[same])
+    assert (p_lb >= 0).mean() > 0.5
+    sc.close()
+
+
+def test_lbvh_on_small_and_degenerate_worlds(gpu, orc, cornell):
+    """Eight leaves (the Cornell box, with coincident box centres on some axes) and
+    a world that is a single leaf."""
+    from raytracing_amd import Scene
+    from raytracing_amd import scene as S
+    lb = gpu.build_lbvh(cornell.flat)
+    gpu.upload_scene(lb)
+    o, d = cornell_ray_batch(cornell, 20000, seed=8)
+    prim, t = gpu.trace_closest(o, d)
+    oprim, ot = orc.trace_closest(lb, o, d, mode=orc.ORC_F32_FUSED)
+    assert np.array_equal(prim, oprim) and np.array_equal(t, ot.astype(np.float32))
+    with Scene(5) as sc:
+        flat = sc.flatten(S.HitableList.new([S.Sphere.new(S.vec3(0, 0, 0), 1.0, S.Lambertian.new_from_color(S.vec3(0.5, 0.5, 0.5)))]))
+        one = gpu.build_lbvh(flat)
+        assert one.n_nodes == 1 and one.nodes[0].left == flat.nodes[0].left
+        gpu.upload_scene(one)
+        prim, t = gpu.trace_closest(np.array([[0, 0, -5]], np.float32), np.array([[0, 0, 1]], np.float32))
+        assert prim[0] == 0 and abs(t[0] - 4.0) < 1e-5
