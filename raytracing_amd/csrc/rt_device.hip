@@ -1,30 +1,35 @@
 // rt_device.hip -- gfx950 kernels and the rt_* entry points of include/rt_abi.h.
 //
-// Two kernels:
-//   trace_kernel  : nearest hit for a batch of rays (the world.hit of main.rs:166).
-//   render_kernel : the whole sample loop of main.rs:96-116 with color()
-//                   (main.rs:165-209) unrolled into an iterative path loop.
+// Kernels:
+//   render_kernel      : the whole sample loop of main.rs:96-116 with color()
+//                        (main.rs:165-209) unrolled into an iterative path loop.
+//   trace_kernel       : nearest hit for a batch of rays (the world.hit of main.rs:166).
+//   reduce_slabs_kernel, tonemap_kernel, selftest_rcp_kernel : small helpers.
 //
-// Execution model.  One wave64 owns an 8x8 pixel tile and the pool of
-// 64*spp (pixel, sample) items of that tile.  Every trip of the path loop each
-// lane advances its path by one vertex; lanes whose path ended are found with a
-// ballot, ranked with mbcnt and refilled from the head of the pool, so the wave
-// stays full until the pool is empty.  Radiance goes to per-tile accumulators in
-// LDS (ds_add_f32) and is written to HBM once, at the end.
+// Execution model of render_kernel.  One single-wave workgroup owns a work item:
+// an 8x8 pixel tile and a chunk of its samples, i.e. a pool of 64*chunk_spp
+// (pixel, sample) paths.  Every trip of the path loop each lane advances its
+// path by one vertex; lanes whose path ended are found with a ballot, ranked with
+// mbcnt and refilled from the head of the pool, so the wave stays full until the
+// pool is empty.  Radiance goes to per-tile accumulators in LDS (ds_add_f32) and
+// is written to HBM once, at the end.  Control flow is wave-uniform; per-lane
+// conditions are selects.
 //
-// Traversal.  For the scene sizes this kernel is built for, 64 incoherent rays
-// visit nearly every node between them, so the wave walks the tree in
-// depth-first order with a wave-uniform node index: node and primitive data
-// arrive through scalar loads into SGPRs, there is no per-lane stack, and each
-// lane only keeps the index of the next node it wants (`lane_next`); a lane whose
-// box test fails sets it to the node's skip link.  Leaves are met in the
-// reference's left-to-right order, so BvhNode::hit's "right wins ties" rule
-// (bvh.rs:212-217) becomes "a later hit replaces the best unless best < t".
+// Traversal, chosen per scene by rt_upload_scene, one kernel build each:
+//   TRAV_FLAT  - a handful of leaves (the Cornell box): the wave walks all of them
+//                with a wave-uniform index, leaf data arriving through scalar loads
+//                into SGPRs; the leaves' box tests are deferred to the winner.
+//   TRAV_SCAN  - the same walk over a depth-first array with skip links.
+//   TRAV_STACK - larger trees: every lane follows its own ray with a stack in LDS.
+// In the first two, leaves are met in the reference's left-to-right order, so
+// BvhNode::hit's "right wins ties" rule (bvh.rs:212-217) becomes "a later hit
+// replaces the best unless best < t"; the third keeps a depth-first rank per leaf.
 //
 // Arithmetic is fp32.  This file is compiled with -ffp-contract=off; every
 // fused multiply-add is written as fmaf() so that the CPU oracle's fp32 "fused"
-// mode can repeat the intersection arithmetic bit for bit.  Divisions and
-// square roots are the correctly rounded ones.
+// mode can repeat the intersection arithmetic bit for bit.  Square roots in the
+// intersection code are the correctly rounded ones, and so is the reciprocal
+// (exact_rcp below).  Shading uses the hardware's approximate instructions.
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -579,8 +584,8 @@ __device__ __forceinline__ void scan_range(const DevScene& S, int begin, int end
 // lane follows its own ray, nearer child first, pruning boxes entered beyond its
 // best hit.  The reference visits both children and lets the right one win an
 // exact tie (bvh.rs:204-217); visiting in another order gives the same winner
-// when a tie goes to the leaf that comes later in depth-first order, so each leaf
-// carries that rank.  A leaf that is a Translate/RotateY over a BvhNode pushes a
+// when a tie goes to the leaf that comes later in depth-first order, so every
+// primitive has the rank of its leaf in prim_rank[], read only on a tie.  A leaf that is a Translate/RotateY over a BvhNode pushes a
 // marker, switches the lane to the object's frame and descends; the marker
 // switches it back.
 template <bool STATS>
