@@ -231,3 +231,31 @@ def test_render_large_image_low_spp(gpu, orc, cornell):
     # the corners and the centre are where an indexing slip would show
     for ys, xs in ((slice(0, 64), slice(0, 64)), (slice(ny - 64, ny), slice(nx - 64, nx)), (slice(1000, 1100), slice(1900, 2000))):
         assert np.isclose(s[ys, xs], o[ys, xs], rtol=2e-4, atol=1e-4).mean() > 0.97
+
+
+def test_cpp_host_program_renders_the_same_image(gpu, tmp_path):
+    """cornell_main (the reference's main() restated in C++ over the library)
+    builds the scene with the C++ host classes, renders and writes a PNG; the Python
+    binding, given the same seed, must produce the same bytes."""
+    import os
+    import subprocess
+    from conftest import ROOT
+    from raytracing_amd import Scene, scenes
+    from raytracing_amd.png import read_png
+    exe = os.path.join(ROOT, "raytracing_amd", "csrc", "cornell_main")
+    assert os.path.exists(exe), "build it with make -C raytracing_amd/csrc"
+    out = str(tmp_path / "cpp.png")
+    seed = 24680
+    run = subprocess.run([exe, "2", "16", out, str(seed)], capture_output=True, text=True, timeout=120)
+    assert run.returncode == 0, run.stderr
+    assert "200x200, 16 samples per pixel, 640000 paths" in run.stdout
+    img_cpp = read_png(out)
+    with Scene(seed) as sc:
+        cam, world = scenes.cornell_box_scene(1.0)
+        sc.light_xz_rect(*scenes.MAIN_RS_LIGHT_SHAPE)
+        flat = sc.flatten(world)
+        gpu.upload_scene(flat)
+        s = gpu.render(cam, make_params(200, 200, 16, seed=seed))
+        img_py = gpu.tonemap(s, 16)
+    assert img_cpp.shape == (200, 200, 3)
+    assert np.array_equal(img_cpp, img_py)

@@ -197,3 +197,24 @@ def test_light_shape_read_from_the_scene_equals_the_hard_coded_one():
         world = S.HitableList.new([S.Sphere.new(S.vec3(0, 0, 0), 1.0, S.Lambertian.new_from_color(S.vec3(0.5, 0.5, 0.5)))])
         assert c.light_from_world(world) == 0
         assert c.flatten(world).n_lights == 0
+
+
+def test_cpp_host_program_fails_loudly_without_a_device(tmp_path):
+    """There is no CPU path: on a machine without a HIP device the C++ program
+    stops with the library's error, not with an image."""
+    import subprocess
+    exe = os.path.join(ROOT, "raytracing_amd", "csrc", "cornell_main")
+    if not os.path.exists(exe):
+        pytest.skip("cornell_main not built")
+    try:
+        import torch
+        if torch.cuda.is_available():
+            pytest.skip("a device is present")
+    except ImportError:
+        pass
+    out = str(tmp_path / "x.png")
+    run = subprocess.run([exe, "1", "1", out], capture_output=True, text=True, timeout=120)
+    assert run.returncode != 0
+    assert "no HIP device" in run.stderr
+    assert not os.path.exists(out)
+    assert subprocess.run([exe, "0"], capture_output=True, text=True, timeout=60).returncode == 2
