@@ -923,9 +923,9 @@ struct RenderArgs {
 // Dielectric, Isotropic and ConstantMedium; 2 adds checker and noise textures.
 template <bool STATS, bool SUMSQ, int TRAV, int GENERAL>
 __global__ void __launch_bounds__(64, GENERAL == 2 ? 4 : ((GENERAL == 1 || TRAV == TRAV_STACK) ? 5 : RT_RENDER_WAVES_PER_SIMD)) render_kernel(DevScene S, DevCamera cam, RenderArgs A, float* __restrict__ out_sum,
-                                                     float* __restrict__ out_sumsq, unsigned long long* __restrict__ stats) {
-  // One single-wave workgroup per work item, so a finished wave frees its slot at
-  // once instead of waiting for the slowest wave of a larger group.
+                                                     float* __restrict__ out_sumsq, unsigned long long* __restrict__ stats, unsigned* __restrict__ queue) {
+  // Single-wave workgroups: every wave is on its own, none waits for the slowest
+  // wave of a larger group.
   __shared__ float acc[1][6][64];
   // A flat scene's primitive tables live in LDS (4 + 2 float4 per primitive, the
   // launch sizes the array): a path vertex then costs no global memory access.
@@ -959,18 +959,28 @@ __global__ void __launch_bounds__(64, GENERAL == 2 ? 4 : ((GENERAL == 1 || TRAV 
     __syncthreads();
   }
   const int wib = 0;
-  // One wave = one work item = (tile, sample chunk).  With more than one chunk
-  // each item writes its partial sums to its own slab; reduce_slabs_kernel adds
-  // the slabs in a fixed order, so the result does not depend on scheduling.
-  const int item = blockIdx.x;
+  Counters cnt;
+  memset(&cnt, 0, sizeof(cnt));
+  // One work item = (tile, sample chunk), run by one wave from start to end.  With
+  // more than one chunk each item writes its partial sums to its own slab;
+  // reduce_slabs_kernel adds the slabs in a fixed order, so the result does not
+  // depend on scheduling.  The launch has one wave per hardware slot and the waves
+  // take items from a counter until none are left: workgroups are handed to the
+  // shader engines in equal numbers although the engines do not have equal numbers
+  // of CUs, so a launch of one workgroup per item leaves the larger engines waiting.
   const int n_tiles = A.tiles_x * A.tiles_y;
-  if (item >= n_tiles * A.n_chunks) return;
+  const int n_items = n_tiles * A.n_chunks;
+  for (;;) {
+  int item = 0;
+  if (lane == 0) item = (int)atomicAdd(queue, 1u);
+  item = __builtin_amdgcn_readfirstlane(item);
+  if (item >= n_items) break;
   const int chunk = item / n_tiles;
   const int tile = item - chunk * n_tiles;
   const int tx = tile % A.tiles_x, ty = tile / A.tiles_x;
   const size_t slab = (size_t)chunk * A.nx * A.ny * 3;
-  out_sum += slab;
-  if (SUMSQ) out_sumsq += slab;
+  float* __restrict__ o_sum = out_sum + slab;
+  float* __restrict__ o_sumsq = SUMSQ ? out_sumsq + slab : nullptr;
   bool mine = true;
   if (A.shard_count > 1) {
     const int big = ((ty * 8) / 64) * ((A.nx + 63) / 64) + (tx * 8) / 64;
@@ -978,9 +988,6 @@ __global__ void __launch_bounds__(64, GENERAL == 2 ? 4 : ((GENERAL == 1 || TRAV 
   }
 #pragma unroll
   for (int c = 0; c < (SUMSQ ? 6 : 3); ++c) acc[wib][c][lane] = 0.0f;
-
-  Counters cnt;
-  memset(&cnt, 0, sizeof(cnt));
 
   const int s_first = chunk * A.chunk_spp;
   const int s_count = mine ? min(A.chunk_spp, A.spp - s_first) : 0;
@@ -1248,16 +1255,17 @@ __global__ void __launch_bounds__(64, GENERAL == 2 ? 4 : ((GENERAL == 1 || TRAV 
     const int row = ty * 8 + (lane >> 3);
     if (px < A.nx && row < A.ny) {
       const size_t at = ((size_t)row * A.nx + px) * 3;
-      out_sum[at] = acc[wib][0][lane];
-      out_sum[at + 1] = acc[wib][1][lane];
-      out_sum[at + 2] = acc[wib][2][lane];
+      o_sum[at] = acc[wib][0][lane];
+      o_sum[at + 1] = acc[wib][1][lane];
+      o_sum[at + 2] = acc[wib][2][lane];
       if (SUMSQ) {
-        out_sumsq[at] = acc[wib][3][lane];
-        out_sumsq[at + 1] = acc[wib][4][lane];
-        out_sumsq[at + 2] = acc[wib][5][lane];
+        o_sumsq[at] = acc[wib][3][lane];
+        o_sumsq[at + 1] = acc[wib][4][lane];
+        o_sumsq[at + 2] = acc[wib][5][lane];
       }
     }
   }
+  }  // next item
   if (STATS) {
     const unsigned v[9] = {cnt.paths, cnt.rays, cnt.hits, cnt.node_tests, cnt.rect_tests, cnt.sphere_tests, cnt.instance_ops, cnt.shade_events, cnt.light_tests};
 #pragma unroll
@@ -1347,6 +1355,8 @@ struct rt_ctx {
   void* d_textures;
   void* d_perlins;
   unsigned long long* d_stats;
+  unsigned* d_queue;    // the work-item counter of render_kernel
+  int n_cus;
   float* d_slabs;       // partial-sum slabs of chunked renders, grown on demand
   size_t slab_floats;
   hipEvent_t ev0, ev1;
@@ -1723,8 +1733,8 @@ int launch_render(rt_ctx* ctx, const rt_camera* cam, const rt_render_params* p, 
   }
   const DevCamera dc = to_dev_camera(cam);
   const int n_items = n_tiles * A.n_chunks;
-  const dim3 grid(n_items), block(64);
-  typedef void (*RenderFn)(DevScene, DevCamera, RenderArgs, float*, float*, unsigned long long*);
+  const dim3 block(64);
+  typedef void (*RenderFn)(DevScene, DevCamera, RenderArgs, float*, float*, unsigned long long*, unsigned*);
 #define RT_TRIO(ST, SQ, TR) render_kernel<ST, SQ, TR, 0>, render_kernel<ST, SQ, TR, 1>, render_kernel<ST, SQ, TR, 2>
 #define RT_ROW(ST, SQ) RT_TRIO(ST, SQ, TRAV_SCAN), RT_TRIO(ST, SQ, TRAV_FLAT), RT_TRIO(ST, SQ, TRAV_STACK)
   static const RenderFn table[36] = {RT_ROW(false, false), RT_ROW(false, true), RT_ROW(true, false), RT_ROW(true, true)};
@@ -1734,7 +1744,12 @@ int launch_render(rt_ctx* ctx, const rt_camera* cam, const rt_render_params* p, 
   const RenderFn fn = table[(stats ? 18 : 0) + (d_sumsq ? 9 : 0) + trav * 3 + ctx->general];
   size_t lds_bytes = trav == TRAV_FLAT ? (size_t)ctx->dev.n_dprims * 6 * sizeof(float4) : 0;
   if (trav == TRAV_STACK) lds_bytes = (size_t)ctx->dev.stack_depth * 64 * sizeof(unsigned);
-  hipLaunchKernelGGL(fn, grid, block, lds_bytes, stream, ctx->dev, dc, A, k_sum, k_sumsq, ctx->d_stats);
+  // One wave for every slot a CU has (8 per SIMD); where the kernel's registers allow fewer, the rest
+  // start when the first waves are done, find no item left and leave.  Never more waves than items.
+  long long waves = 32LL * (ctx->n_cus > 0 ? ctx->n_cus : 1);
+  if (waves > n_items) waves = n_items;
+  HIP_TRY(hipMemsetAsync(ctx->d_queue, 0, sizeof(unsigned), stream));
+  hipLaunchKernelGGL(fn, dim3((unsigned)waves), block, lds_bytes, stream, ctx->dev, dc, A, k_sum, k_sumsq, ctx->d_stats, ctx->d_queue);
   HIP_TRY(hipGetLastError());
   if (A.n_chunks > 1) {
     const size_t n4 = n / 4;
@@ -1763,7 +1778,11 @@ int rt_create(int device_id, rt_ctx** out) {
   rt_ctx* ctx = new rt_ctx();
   std::memset(ctx, 0, sizeof(*ctx));
   ctx->device = device_id;
-  e = hipMalloc((void**)&ctx->d_stats, 9 * sizeof(unsigned long long));
+  hipDeviceProp_t prop;
+  e = hipGetDeviceProperties(&prop, device_id);
+  ctx->n_cus = e == hipSuccess ? prop.multiProcessorCount : 0;
+  if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_stats, 9 * sizeof(unsigned long long));
+  if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_queue, sizeof(unsigned));
   if (e == hipSuccess) e = hipEventCreate(&ctx->ev0);
   if (e == hipSuccess) e = hipEventCreate(&ctx->ev1);
   if (e != hipSuccess) {
@@ -1779,6 +1798,7 @@ int rt_destroy(rt_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   free_scene(ctx);
   if (ctx->d_stats) (void)hipFree(ctx->d_stats);
+  if (ctx->d_queue) (void)hipFree(ctx->d_queue);
   if (ctx->d_slabs) (void)hipFree(ctx->d_slabs);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
