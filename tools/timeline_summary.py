@@ -1,3 +1,11 @@
+#!/usr/bin/env python3
+"""Summarises a work-item timeline written by a library built with
+tools/timeline_build.py (RT_TIMELINE_OUT=<file>): item durations, waves in flight
+over time, waves per SIMD in steady state by XCD / shader engine / CU / SIMD, and the
+idle time between two items on one hardware wave slot.
+
+  python tools/timeline_summary.py /tmp/tl.bin
+"""
 import numpy as np, sys
 a=np.fromfile(sys.argv[1],dtype=np.uint64).reshape(-1,3)
 st=a[:,0].astype(np.int64); en=a[:,1].astype(np.int64)
