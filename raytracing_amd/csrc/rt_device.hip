@@ -32,6 +32,7 @@
 // (exact_rcp below).  Shading uses the hardware's approximate instructions.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -142,8 +143,8 @@ struct BNode {
 struct BNode2 {
   float lmin[3]; int left;
   float lmax[3]; int right;
-  float rmin[3]; int pad0;
-  float rmax[3]; int pad1;
+  float rmin[3]; float l_top;  // y_top of the children (see slab_core)
+  float rmax[3]; float r_top;
 };
 #define BN2_LEAF 0x40000000
 #define BN2_PRIM 0x20000000  // with BN2_LEAF: a single-primitive leaf, the low bits are the primitive's index
@@ -321,36 +322,46 @@ __device__ __forceinline__ Signs ray_signs(const RayF& r) {
   s.z = r.inv.z < 0.0f;
   return s;
 }
-__device__ __forceinline__ bool slab_box(float x0, float y0, float z0, float x1, float y1, float z1, const RayF& r, const Signs& sg,
-                                         float t_min, float t_max, float best_t) {
+// `y_top` (>= y1) is how high the geometry under the box really reaches: a Cuboid's
+// top face lies 0.01 above the cuboid's own box (hitable.rs:398-399), so a ray coming
+// down can hit it before it enters the box.  The box test itself uses the box, as the
+// reference does; the pruning test uses the entry distance into the box raised to
+// y_top, which no hit under this node can undercut.
+__device__ __forceinline__ bool slab_core(float x0, float y0, float z0, float x1, float y1, float z1, float y_top, const RayF& r,
+                                          const Signs& sg, float t_min, float t_max, float best_t, float& t_enter) {
+  const float t_min0 = t_min;
   float t0 = (x0 - r.o.x) * r.inv.x, t1 = (x1 - r.o.x) * r.inv.x;
-  t_min = fmaxf(sg.x ? t1 : t0, t_min);
+  const float nx = sg.x ? t1 : t0;
+  t_min = fmaxf(nx, t_min);
   t_max = fminf(sg.x ? t0 : t1, t_max);
   t0 = (y0 - r.o.y) * r.inv.y; t1 = (y1 - r.o.y) * r.inv.y;
-  t_min = fmaxf(sg.y ? t1 : t0, t_min);
+  const float ny = sg.y ? t1 : t0;
+  t_min = fmaxf(ny, t_min);
   t_max = fminf(sg.y ? t0 : t1, t_max);
   t0 = (z0 - r.o.z) * r.inv.z; t1 = (z1 - r.o.z) * r.inv.z;
-  t_min = fmaxf(sg.z ? t1 : t0, t_min);
-  t_max = fminf(sg.z ? t0 : t1, t_max);
-  return !(t_max <= t_min) & !(t_min > best_t);
-}
-// The same test, also handing back where the ray enters the box (meaningful when it does).
-__device__ __forceinline__ bool slab_box_enter(float4 lo, float4 hi, const RayF& r, const Signs& sg, float t_min, float t_max, float best_t,
-                                               float& t_enter) {
-  float t0 = (lo.x - r.o.x) * r.inv.x, t1 = (hi.x - r.o.x) * r.inv.x;
-  t_min = fmaxf(sg.x ? t1 : t0, t_min);
-  t_max = fminf(sg.x ? t0 : t1, t_max);
-  t0 = (lo.y - r.o.y) * r.inv.y; t1 = (hi.y - r.o.y) * r.inv.y;
-  t_min = fmaxf(sg.y ? t1 : t0, t_min);
-  t_max = fminf(sg.y ? t0 : t1, t_max);
-  t0 = (lo.z - r.o.z) * r.inv.z; t1 = (hi.z - r.o.z) * r.inv.z;
-  t_min = fmaxf(sg.z ? t1 : t0, t_min);
+  const float nz = sg.z ? t1 : t0;
+  t_min = fmaxf(nz, t_min);
   t_max = fminf(sg.z ? t0 : t1, t_max);
   t_enter = t_min;
-  return !(t_max <= t_min) & !(t_min > best_t);
+  const float ny_top = sg.y ? (y_top - r.o.y) * r.inv.y : ny;
+  const float t_prune = fmaxf(fmaxf(nx, nz), fmaxf(ny_top, t_min0));
+  return !(t_max <= t_min) & !(t_prune > best_t);
 }
+// Without pruning (best_t = +inf) y_top plays no part.
+__device__ __forceinline__ bool slab_box(float x0, float y0, float z0, float x1, float y1, float z1, const RayF& r, const Signs& sg,
+                                         float t_min, float t_max) {
+  float te;
+  return slab_core(x0, y0, z0, x1, y1, z1, y1, r, sg, t_min, t_max, 3.402823466e+38f, te);
+}
+// The same with pruning against best_t, also handing back where the ray enters the box (meaningful when it does).
+__device__ __forceinline__ bool slab_box_enter(float4 lo, float4 hi, float y_top, const RayF& r, const Signs& sg, float t_min, float t_max,
+                                               float best_t, float& t_enter) {
+  return slab_core(lo.x, lo.y, lo.z, hi.x, hi.y, hi.z, y_top, r, sg, t_min, t_max, best_t, t_enter);
+}
+// A scan node keeps its y_top in f[5].
 __device__ __forceinline__ bool slab_test(const ScanNode& n, const RayF& r, const Signs& sg, float t_min, float t_max, float best_t) {
-  return slab_box(n.bmin[0], n.bmin[1], n.bmin[2], n.bmax[0], n.bmax[1], n.bmax[2], r, sg, t_min, t_max, best_t);
+  float te;
+  return slab_core(n.bmin[0], n.bmin[1], n.bmin[2], n.bmax[0], n.bmax[1], n.bmax[2], n.f[5], r, sg, t_min, t_max, best_t, te);
 }
 
 // XYRect/XZRect/YZRect::hit (hitable.rs:163-173 and twins).  C is the fixed
@@ -637,7 +648,7 @@ __device__ __forceinline__ void trace_stack(const DevScene& S, unsigned* __restr
     const float4 hi = *((const float4*)&S.bnodes[0] + 1);
     float te;
     if (STATS) cnt.node_tests++;
-    const bool h = slab_box_enter(lo, hi, r, sg, t_min, t_max, best.t, te);
+    const bool h = slab_box_enter(lo, hi, hi.y, r, sg, t_min, t_max, 3.402823466e+38f, te);  // nothing to prune against yet
     cur = h ? (S.bnodes[0].left < 0 ? BN2_LEAF : 0) : POP;
   }
   for (;;) {
@@ -657,8 +668,8 @@ __device__ __forceinline__ void trace_stack(const DevScene& S, unsigned* __restr
       const float4* rec = (const float4*)&S.bnodes2[cur];
       const float4 llo = rec[0], lhi = rec[1], rlo = rec[2], rhi = rec[3];
       float tl, tr;
-      const bool hl = slab_box_enter(llo, lhi, r, sg, t_min, t_max, best.t, tl);
-      const bool hr = slab_box_enter(rlo, rhi, r, sg, t_min, t_max, best.t, tr);
+      const bool hl = slab_box_enter(llo, lhi, rlo.w, r, sg, t_min, t_max, best.t, tl);  // the spare words hold the children's y_top
+      const bool hr = slab_box_enter(rlo, rhi, rhi.w, r, sg, t_min, t_max, best.t, tr);
       if (STATS) cnt.node_tests += 2;
       const int left = __float_as_int(llo.w), right = __float_as_int(lhi.w);
       const bool left_first = !(tr < tl);
@@ -700,7 +711,7 @@ __device__ __forceinline__ void trace_stack(const DevScene& S, unsigned* __restr
       const float4 hi = *((const float4*)&S.bnodes[ob.first] + 1);
       float te;
       if (STATS) cnt.node_tests++;
-      const bool h = slab_box_enter(lo, hi, r, sg, t_min, t_max, best.t, te);
+      const bool h = slab_box_enter(lo, hi, hi.y, r, sg, t_min, t_max, 3.402823466e+38f, te);  // the sub-tree's root: box test only
       cur = h ? (ob.first | (S.bnodes[ob.first].left < 0 ? BN2_LEAF : 0)) : POP;
     }
   }
@@ -734,7 +745,7 @@ __device__ __forceinline__ Hit trace_scan(const DevScene& S, unsigned* stk, cons
     const float4* lb = leaf_box + 2 * (got ? best.prim : 0);
     const float4 b0 = lb[0], b1 = lb[1];
     if (STATS) cnt.node_tests += got;
-    const bool ok = slab_box(b0.x, b0.y, b0.z, b1.x, b1.y, b1.z, w, ray_signs(w), t_min, t_max, 3.402823466e+38f);
+    const bool ok = slab_box(b0.x, b0.y, b0.z, b1.x, b1.y, b1.z, w, ray_signs(w), t_min, t_max);
     if (__builtin_expect(__ballot(got & !ok) != 0ull, 0)) {
       best.t = t_max;
       best.prim = -1;
@@ -1480,6 +1491,7 @@ struct ScanBuilder {
   std::vector<ScanNode> out;
   std::vector<int> prim_obj;
   std::vector<float> leaf_box;  // 8 floats per primitive: the box of the scan leaf that holds it
+  std::vector<float> y_top;     // per node, see compute_y_top
   std::vector<int> media;  // object index of each ConstantMedium, in scan order
   bool any_interior;
   void set_leaf_box(int prim, const rt_node& n) {
@@ -1517,10 +1529,59 @@ void push_box6(const rt_scene* s, int first, std::vector<ScanNode>* out) {
   out->push_back(ext[1]);
 }
 
-ScanNode box_node(const rt_node& n) {
+// The smallest float not below v, moved up two more steps to cover the rounding of
+// the device's own fp32 arithmetic on the way to a hit point.
+float round_up(double v) {
+  float f = (float)v;
+  if ((double)f < v) f = std::nextafter(f, INFINITY);
+  return std::nextafter(std::nextafter(f, INFINITY), INFINITY);
+}
+
+// How high the primitives of prims[first, first+count) reach, in their own frame.
+double geometry_top(const rt_scene* s, int first, int count) {
+  double top = -INFINITY;
+  for (int k = first; k < first + count; ++k) {
+    const rt_prim& q = s->prims[k];
+    const int type = q.type & RT_PRIM_TYPE_MASK;
+    const double y = type == RT_PRIM_SPHERE ? (double)q.f[1] + std::fabs((double)q.f[3])
+                   : type == RT_PRIM_XY_RECT ? (double)q.f[3] : (type == RT_PRIM_XZ_RECT ? (double)q.f[4] : (double)q.f[1]);
+    if (y > top) top = y;
+  }
+  return top;
+}
+
+// y_top of every node (see slab_core): the node's box top, raised where the
+// geometry under it reaches higher, which in the reference's constructors is the
+// top face of a Cuboid (hitable.rs:398-399).  Nodes of an object's sub-tree get
+// theirs in the object's frame; RotateY and Translate leave heights as they are
+// up to the offset.
+float compute_y_top(const rt_scene* s, int idx, int depth, std::vector<float>* y_top) {
+  // Runs before the tree has been checked: anything out of range is left alone here
+  // and reported by build_scan.
+  if (idx < 0 || idx >= s->n_nodes || depth > 130) return -INFINITY;
+  const rt_node& n = s->nodes[idx];
+  float top = n.bmax[1];
+  if (n.left >= 0) {
+    top = std::max(top, compute_y_top(s, n.left, depth + 1, y_top));
+    top = std::max(top, compute_y_top(s, n.right, depth + 1, y_top));
+  } else if (n.right > 0) {
+    const int ref = ~n.left;
+    if (ref >= 0 && ref <= s->n_prims - n.right) top = std::max(top, round_up(geometry_top(s, ref, n.right)));
+  } else if (~n.left < s->n_objects) {
+    const rt_object& ob = s->objects[~n.left];
+    const double lift = (ob.xform & RT_XFORM_TRANSLATE) ? (double)ob.offset[1] : 0.0;
+    const double inner = ob.kind == RT_OBJ_BVH ? (double)compute_y_top(s, ob.first, depth + 1, y_top) : geometry_top(s, ob.first, ob.count);
+    top = std::max(top, round_up(inner + lift));
+  }
+  (*y_top)[(size_t)idx] = top;
+  return top;
+}
+
+ScanNode box_node(const rt_node& n, float y_top) {
   ScanNode sn;
   std::memset(&sn, 0, sizeof(sn));
   for (int c = 0; c < 3; ++c) { sn.bmin[c] = n.bmin[c]; sn.bmax[c] = n.bmax[c]; }
+  sn.f[5] = y_top;
   return sn;
 }
 
@@ -1535,7 +1596,7 @@ int build_scan(ScanBuilder* B, int idx, bool in_sub, bool collapsed, bool tree_r
     const bool emit = !collapsed && !(small && tree_root);
     const size_t at = B->out.size();
     if (emit) {
-      ScanNode sn = box_node(n);
+      ScanNode sn = box_node(n, B->y_top[(size_t)idx]);
       sn.kind = K_INTERIOR;
       B->out.push_back(sn);
       B->any_interior = true;
@@ -1547,7 +1608,7 @@ int build_scan(ScanBuilder* B, int idx, bool in_sub, bool collapsed, bool tree_r
     if (emit) B->out[at].skip = (int)B->out.size();
     return RT_OK;
   }
-  ScanNode sn = box_node(n);
+  ScanNode sn = box_node(n, B->y_top[(size_t)idx]);
   const int ref = ~n.left;
   if (n.right > 0) {
     if (ref < 0 || ref + n.right > s->n_prims) return rt::set_error(RT_ERR_INVALID, "leaf primitive range out of bounds");
@@ -1559,7 +1620,7 @@ int build_scan(ScanBuilder* B, int idx, bool in_sub, bool collapsed, bool tree_r
       const rt_prim& q = s->prims[ref];
       const int type = q.type & RT_PRIM_TYPE_MASK;
       sn.kind = type == RT_PRIM_SPHERE ? K_SPHERE : (type == RT_PRIM_XY_RECT ? K_RECT_XY : (type == RT_PRIM_XZ_RECT ? K_RECT_XZ : K_RECT_YZ));
-      for (int k = 0; k < 6; ++k) sn.f[k] = q.f[k];
+      for (int k = 0; k < 5; ++k) sn.f[k] = q.f[k];
       sn.a = ref;
       sn.b = 1;
     } else {
@@ -1818,6 +1879,8 @@ int rt_upload_scene(rt_ctx* ctx, const rt_scene* s) {
   B.any_interior = false;
   rc = count_leaves(s, 0, 0, &B.leaves);
   if (rc < 0) return rc;
+  B.y_top.assign((size_t)s->n_nodes, 0.0f);
+  (void)compute_y_top(s, 0, 0, &B.y_top);
   rc = build_scan(&B, 0, false, false, true, -1);
   if (rc != RT_OK) return rc;
   // More than a treelet's worth of leaves: per-lane stack traversal over the
@@ -1907,6 +1970,8 @@ int rt_upload_scene(rt_ctx* ctx, const rt_scene* s) {
       };
       b.left = ref_of(n.left, l);
       b.right = ref_of(n.right, r);
+      b.l_top = B.y_top[(size_t)n.left];
+      b.r_top = B.y_top[(size_t)n.right];
     }
   }
   if ((rc = upload(&ctx->d_bnodes2, bnodes2.data(), bnodes2.size())) != RT_OK) return rc;
