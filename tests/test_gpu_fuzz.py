@@ -72,3 +72,27 @@ def test_random_scenes_trace_bit_exact(gpu, orc, seed, n_items):
         prim2, t2 = gpu.trace_closest(o, d)
         oprim2, ot2 = orc.trace_closest(lb, o, d, mode=orc.ORC_F32_FUSED)
         assert np.array_equal(prim2, oprim2) and np.array_equal(t2, ot2.astype(np.float32))
+
+
+@pytest.mark.parametrize("seed,n_items,media", [(21, 6, 1), (22, 14, 2), (23, 40, 1), (24, 150, 0), (25, 10, 0)])
+def test_random_scenes_render_tracks_oracle(gpu, orc, seed, n_items, media):
+    """Random scenes with every material, constant media in random boxes, a lamp
+    and the gradient sky, through the flat and the stack layouts: same random
+    stream against the fp32 oracle, independent streams against the f64 oracle."""
+    from raytracing_amd import _lib
+    from test_gpu_materials import _compare
+    rng = np.random.RandomState(2000 + seed)
+    with Scene(seed) as sc:
+        mats = [S.Lambertian.new_from_color(S.vec3(*(0.2 + 0.6 * rng.rand(3)))), S.Metal.new(S.vec3(0.8, 0.7, 0.6), 0.2),
+                S.Dielectric.new(1.5), S.Lambertian.new_from_color(S.vec3(0.7, 0.7, 0.7))]
+        items = [_random_hitable(rng, mats) for _ in range(n_items)]
+        items.append(S.Sphere.new(S.vec3(0.0, -1010.0, 0.0), 1000.0, mats[3]))
+        items.append(S.FlipNormals.new_xz(S.XZRect.new(-4.0, 4.0, -4.0, 4.0, 14.0, S.DiffuseLight.new(S.Texture.new_constant(S.scalar(8.0))))))
+        for _ in range(media):
+            box = S.Translate.new(S.RotateY.new(S.Cuboid.new(S.vec3(0, 0, 0), S.vec3(*rng.uniform(3, 8, 3)), mats[0]), float(rng.uniform(-40, 40))),
+                                  S.vec3(*rng.uniform(-8, 2, 3)))
+            items.append(S.ConstantMedium.new(box, float(rng.uniform(0.05, 0.3)), S.Texture.new_constant(S.vec3(*rng.rand(3)))))
+        sc.light_xz_rect(-4.0, 4.0, -4.0, 4.0, 14.0)
+        cam = S.Camera.new(S.vec3(0.0, 6.0, -34.0), S.vec3(0.0, 0.0, 0.0), S.vec3(0.0, 1.0, 0.0), 40.0, 1.5, 0.0, 10.0)
+        flat = sc.flatten(S.HitableList.new(items))
+        _compare(gpu, orc, flat, cam, 48, 32, 48, sky=_lib.RT_SKY_GRADIENT, same_frac=0.75, energy_tol=0.03)
