@@ -134,7 +134,7 @@ struct BNode {
   float bmax[3];
   int right;
 };
-#define BN_INDEX_MASK 0x1fffffff
+#define BN_INDEX_MASK 0x0fffffff
 // What the stack traversal fetches at an interior node: the boxes of its two
 // children and where they are, 64 bytes, so each fetch decides two box tests and
 // a leaf's box never costs a fetch of its own.  A child reference is the child's
@@ -148,6 +148,7 @@ struct BNode2 {
 };
 #define BN2_LEAF 0x40000000
 #define BN2_PRIM 0x20000000  // with BN2_LEAF: a single-primitive leaf, the low bits are the primitive's index
+#define BN2_INLINE 0x10000000  // with BN2_PRIM: test the primitive inside the descent loop (scenes whose leaves are all single primitives)
 #define STACK_DEPTH 64  // deepest tree the stack traversal takes; the launch sizes the LDS stack to the scene's own depth
 #define STACK_RESTORE 0xffffffffu
 
@@ -652,18 +653,27 @@ __device__ __forceinline__ void trace_stack(const DevScene& S, unsigned* __restr
     cur = h ? (S.bnodes[0].left < 0 ? BN2_LEAF : 0) : POP;
   }
   for (;;) {
-    if (cur == POP) {
-      if (sp == 0) break;
-      --sp;
-      const unsigned x = stk[sp * 64];
-      if (x == STACK_RESTORE) {
-        r = w;
-        sg = ray_signs(r);
+    // down through interior nodes until this lane holds a leaf (lanes that have one wait for the rest of the wave,
+    // so the leaf code below runs once for many lanes instead of once per step)
+    for (;;) {
+      if (cur == POP) {
+        if (sp == 0) break;
+        --sp;
+        const unsigned x = stk[sp * 64];
+        if (x == STACK_RESTORE) {
+          r = w;
+          sg = ray_signs(r);
+          continue;
+        }
+        cur = (int)x;
+      }
+      if (cur & BN2_LEAF) {
+        if (!(cur & BN2_INLINE)) break;
+        // every leaf of this scene is one primitive: cheap enough to test in step with the other lanes' interior nodes
+        prim_list_lane<STATS>(S, cur & BN_INDEX_MASK, 1, r, t_min, t_max, best, cnt);
+        cur = POP;
         continue;
       }
-      cur = (int)x;
-    }
-    if (!(cur & BN2_LEAF)) {
       // interior: both children's boxes from one 64-byte record
       const float4* rec = (const float4*)&S.bnodes2[cur];
       const float4 llo = rec[0], lhi = rec[1], rlo = rec[2], rhi = rec[3];
@@ -680,17 +690,17 @@ __device__ __forceinline__ void trace_stack(const DevScene& S, unsigned* __restr
       } else {
         cur = hl ? left : (hr ? right : POP);
       }
-      continue;
     }
+    if (cur == POP) break;
     // a leaf whose box the ray has passed
     const int node = cur & BN_INDEX_MASK;
     const bool single = (cur & BN2_PRIM) != 0;
     cur = POP;
-    if (single) {
-      prim_list_lane<STATS>(S, node, 1, r, t_min, t_max, best, cnt);
-      continue;
+    int ref = node, count = 1;
+    if (!single) {
+      ref = ~S.bnodes[node].left;
+      count = S.bnodes[node].right;
     }
-    const int ref = ~S.bnodes[node].left, count = S.bnodes[node].right;
     if (count > 0) {
       prim_list_lane<STATS>(S, ref, count, r, t_min, t_max, best, cnt);
       continue;
@@ -1957,6 +1967,11 @@ int rt_upload_scene(rt_ctx* ctx, const rt_scene* s) {
   if (stack_mode) {
     bnodes2.assign((size_t)s->n_nodes, BNode2());
     std::memset(bnodes2.data(), 0, bnodes2.size() * sizeof(BNode2));
+    // With lists or instances at some leaves the wave gathers its lanes at the leaf code; when every leaf is one
+    // primitive the test is cheap and runs inside the descent loop.
+    int inline_single = BN2_INLINE;
+    for (int i = 0; i < s->n_nodes; ++i)
+      if (s->nodes[i].left < 0 && s->nodes[i].right != 1) inline_single = 0;
     for (int i = 0; i < s->n_nodes; ++i) {
       const rt_node& n = s->nodes[i];
       if (n.left < 0) continue;
@@ -1964,9 +1979,9 @@ int rt_upload_scene(rt_ctx* ctx, const rt_scene* s) {
       const rt_node& r = s->nodes[n.right];
       BNode2& b = bnodes2[(size_t)i];
       for (int c = 0; c < 3; ++c) { b.lmin[c] = l.bmin[c]; b.lmax[c] = l.bmax[c]; b.rmin[c] = r.bmin[c]; b.rmax[c] = r.bmax[c]; }
-      auto ref_of = [](int child, const rt_node& c) {
+      auto ref_of = [inline_single](int child, const rt_node& c) {
         if (c.left >= 0) return child;
-        return c.right == 1 ? (BN2_LEAF | BN2_PRIM | ~c.left) : (BN2_LEAF | child);
+        return c.right == 1 ? (BN2_LEAF | BN2_PRIM | inline_single | ~c.left) : (BN2_LEAF | child);
       };
       b.left = ref_of(n.left, l);
       b.right = ref_of(n.right, r);
