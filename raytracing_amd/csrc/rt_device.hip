@@ -991,6 +991,12 @@ __global__ void __launch_bounds__(64, GENERAL == 2 ? 4 : ((GENERAL == 1 || TRAV 
   // of CUs, so a launch of one workgroup per item leaves the larger engines waiting.
   const int n_tiles = A.tiles_x * A.tiles_y;
   const int n_items = n_tiles * A.n_chunks;
+  // The kernel's arguments arrive as sixteen-register loads, and a value used from one
+  // keeps all sixteen alive (and spilled and reloaded together) for the life of the
+  // loop.  The ones the path loop reads are copied to registers of their own here.
+  float a_t_min = A.t_min;
+  int a_max_depth = A.max_depth, a_sky = A.sky;
+  asm volatile("" : "+s"(a_t_min), "+s"(a_max_depth), "+s"(a_sky));
   for (;;) {
   int item = 0;
   if (lane == 0) item = (int)atomicAdd(queue, 1u);
@@ -1103,7 +1109,7 @@ __global__ void __launch_bounds__(64, GENERAL == 2 ? 4 : ((GENERAL == 1 || TRAV 
     // ---- world.hit(r, 0.001, INFINITY), main.rs:166 ----
     if (STATS) cnt.rays += alive;
     const PathRng rng = {pixel_id, sample, (unsigned)depth, key0, key1};
-    const Hit h = trace_scan<STATS, TRAV, GENERAL != 0>(S, stk, box_tab, alive, ray, A.t_min, INFINITY, rng, cnt);
+    const Hit h = trace_scan<STATS, TRAV, GENERAL != 0>(S, stk, box_tab, alive, ray, a_t_min, INFINITY, rng, cnt);
 
     // ---- color(), main.rs:165-209, one vertex; every lane runs it, dead lanes and
     // misses on primitive 0 with their results masked ----
@@ -1131,7 +1137,7 @@ __global__ void __launch_bounds__(64, GENERAL == 2 ? 4 : ((GENERAL == 1 || TRAV 
     const bool emits = hit & is_light & (dot3(sf.normal, ray.d) < 0.0f);
     // main.rs:203-208
     F3 sky = f3(0, 0, 0);
-    if (A.sky == RT_SKY_GRADIENT) {
+    if (a_sky == RT_SKY_GRADIENT) {
       const F3 ud = unit3(ray.d);
       const float t = 0.5f * (ud.y + 1.0f);
       sky = f3((1.0f - t) + t * 0.5f, (1.0f - t) + t * 0.7f, (1.0f - t) + t * 1.0f);
@@ -1140,7 +1146,7 @@ __global__ void __launch_bounds__(64, GENERAL == 2 ? 4 : ((GENERAL == 1 || TRAV 
     const F3 radiance = f3(thr.x * le.x, thr.y * le.y, thr.z * le.z);  // what this vertex adds to the sample, before de_nan
 
     // Lambertian under MixturePDF(HitablePDF(light), CosinePDF(normal)), main.rs:173-197.
-    const bool scatters = hit & (mat_type == RT_MAT_LAMBERTIAN) & (depth < A.max_depth);
+    const bool scatters = hit & (mat_type == RT_MAT_LAMBERTIAN) & (depth < a_max_depth);
     if (STATS) cnt.shade_events += scatters;
     const float xi1 = u01(w.z), xi2 = u01(w.w);
     // onb.rs:10-21.  The normal is already of unit length (to rounding), and the cross
@@ -1189,7 +1195,7 @@ __global__ void __launch_bounds__(64, GENERAL == 2 ? 4 : ((GENERAL == 1 || TRAV 
       // Materials of the reference's older scatter() -> (attenuation, ray) form
       // (material.rs:100-112, 125-159, 217-221, commented out there): the path goes on
       // along the returned ray weighted by the attenuation, with no pdf involved.
-      const bool deep = depth < A.max_depth;
+      const bool deep = depth < a_max_depth;
       const bool is_metal = hit & deep & (mat_type == RT_MAT_METAL);
       const bool is_diel = hit & deep & (mat_type == RT_MAT_DIELECTRIC);
       const bool is_iso = hit & deep & (mat_type == RT_MAT_ISOTROPIC);
