@@ -163,6 +163,14 @@ def main():
                       "reference's way (8 threads, each the whole image at spp/8, then summed), not the Rust binary"
                       % (args.cpu_spp, cdt),
         }
+        # the same sample on this job's whole CPU share (16 hardware threads per GPU on the benchmark hosts)
+        share = min(16, os.cpu_count() or 1)
+        if share > cpu_threads:
+            c0 = time.perf_counter()
+            orc.render(flat, cam.c, cp, mode=orc.ORC_F64, n_threads=share, split_samples=True, want_sumsq=False, want_stats=False)
+            cdt = time.perf_counter() - c0
+            cpu["all_cores"] = {"value": round(nx * ny * args.cpu_spp / cdt / 1e6, 3), "unit": "Mpaths/s", "cores": share,
+                                "sample": "the same sample on %d threads (%.1f s)" % (share, cdt)}
 
     roofline = None
     if ref_flops_per_path is not None:
