@@ -55,6 +55,8 @@ def main():
     ap.add_argument("--cpu-spp", type=int, default=256, help="samples per pixel of the CPU baseline's bounded run")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stats", action="store_true")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="N ranks share GPU 0 and exchange over gloo: checks the multi-rank control flow on a one-GPU box, not a benchmark")
     args = ap.parse_args()
 
     import torch
@@ -67,10 +69,15 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
         raise SystemExit("WORLD_SIZE=%d does not match --gpus %d" % (world, args.gpus))
+    if args.rehearse_on_one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if args.rehearse_on_one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     from raytracing_amd import Renderer, Scene, make_params
     from raytracing_amd.scenes import MAIN_RS_LIGHT_SHAPE, cornell_box_scene
@@ -97,7 +104,12 @@ def main():
         r.render_device(cam, params, buf.data_ptr(), None, stream.cuda_stream)
         if ev1 is not None:
             ev1.record(stream)
-        reduce_to_root(buf)
+        if args.rehearse_on_one_gpu and world > 1:
+            host = buf.cpu()  # gloo exchanges host tensors
+            reduce_to_root(host)
+            buf.copy_(host)
+        else:
+            reduce_to_root(buf)
 
     def fence():
         torch.cuda.synchronize(dev)
@@ -105,15 +117,23 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    def note(what):
+        if args.rehearse_on_one_gpu:
+            print("[rank %d] %s" % (rank, what), file=sys.stderr, flush=True)
+
+    note("scene uploaded")
     for _ in range(args.warmup):
         step()
+    note("warm-up steps done")
     fence()
+    note("first fence passed")
     events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     t0 = time.perf_counter()
     for k in range(args.steps):
         step(*events[k])
     fence()
     elapsed = time.perf_counter() - t0
+    note("timed steps done")
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -203,7 +223,8 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "cornell_box_scene (scenes.rs:276-360) %dx%d @ %d spp, MixturePDF light sampling, "
                                    "max depth 50" % (nx, ny, spp),
-                       "sharding": "sample range per GPU + RCCL reduce(sum) to rank 0" if world > 1 else "single GPU",
+                       "sharding": ("REHEARSAL: ranks share one GPU, gloo exchange" if args.rehearse_on_one_gpu else
+                                    "sample range per GPU + RCCL reduce(sum) to rank 0") if world > 1 else "single GPU",
                        "seed": seed},
             "roofline": roofline,
             "cpu_baseline": cpu,
