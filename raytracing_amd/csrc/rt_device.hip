@@ -926,7 +926,8 @@ struct RenderArgs {
   int shard_index, shard_count;
   unsigned key0, key1;
   int tiles_x, tiles_y;
-  int n_chunks, chunk_spp;  // the samples of a tile are split into n_chunks work items of chunk_spp samples
+  int n_chunks, chunk_spp;  // the samples of a tile are split into n_chunks work items of chunk_spp samples,
+  int split_parts;          // the last of which is cut into this many parts, each half the one before
 };
 
 // Waves per SIMD the register allocator must leave room for (launch_bounds' second argument).
@@ -1016,8 +1017,19 @@ __global__ void __launch_bounds__(64, (GENERAL != 0 || TRAV == TRAV_STACK) ? 5 :
 #pragma unroll
   for (int c = 0; c < (SUMSQ ? 6 : 3); ++c) acc[wib][c][lane] = 0.0f;
 
-  const int s_first = chunk * A.chunk_spp;
-  const int s_count = mine ? min(A.chunk_spp, A.spp - s_first) : 0;
+  // Items are handed out chunk by chunk, so the launch ends on the last chunk's items:
+  // that chunk comes in halving parts, which keeps the waves' finishing times close.
+  const int n_whole = A.n_chunks - A.split_parts;
+  int s_first = chunk * A.chunk_spp, s_len = A.chunk_spp;
+  if (chunk >= n_whole) {
+    const int k = chunk - n_whole;
+    const int last = A.spp - n_whole * A.chunk_spp;
+    const int o0 = last - (last >> k);
+    const int o1 = k + 1 < A.split_parts ? last - (last >> (k + 1)) : last;
+    s_first = n_whole * A.chunk_spp + o0;
+    s_len = o1 - o0;
+  }
+  const int s_count = mine ? s_len : 0;
   const int pool_size = 64 * s_count;  // a tile of another shard is written as zeros
   int pool_next = 0;
 
@@ -1794,6 +1806,17 @@ int launch_render(rt_ctx* ctx, const rt_camera* cam, const rt_render_params* p, 
   A.n_chunks = (int)chunks;
   A.chunk_spp = (p->spp + A.n_chunks - 1) / A.n_chunks;
   A.n_chunks = (p->spp + A.chunk_spp - 1) / A.chunk_spp;
+  // the last chunk in up to four halving parts of at least 8 samples (see the kernel; sizes measured
+  // on five scenes: smaller parts cost more at the end of each item than they save at the end of the launch)
+  A.split_parts = 1;
+  if ((n % 4) == 0) {
+    const int last = p->spp - (A.n_chunks - 1) * A.chunk_spp;
+    while (A.split_parts < 4 && (last >> A.split_parts) >= 8 &&
+           (size_t)(A.n_chunks + 1) * per_image * sizeof(float) <= ((size_t)1 << 30)) {
+      ++A.split_parts;
+      ++A.n_chunks;
+    }
+  }
   float* k_sum = d_sum;
   float* k_sumsq = d_sumsq;
   if (A.n_chunks > 1) {
