@@ -247,13 +247,14 @@ __device__ __forceinline__ RayF to_object_frame(const RayF& w, int xform, float 
 }
 
 __device__ __forceinline__ ScanNode load_node(const ScanNode* base, int i) {
-  const u32x16 v = *(const RT_CONSTANT_AS u32x16*)(base + i);
+  // a 32-bit unsigned byte offset goes straight into the scalar load's offset operand (no 64-bit address arithmetic)
+  const u32x16 v = *(const RT_CONSTANT_AS u32x16*)((const RT_CONSTANT_AS char*)base + (unsigned)i * 64u);
   ScanNode n;
   __builtin_memcpy(&n, &v, sizeof(n));
   return n;
 }
 __device__ __forceinline__ rt_prim load_prim_uniform(const rt_prim* base, int i) {
-  const u32x8 v = *(const RT_CONSTANT_AS u32x8*)(base + i);
+  const u32x8 v = *(const RT_CONSTANT_AS u32x8*)((const RT_CONSTANT_AS char*)base + (unsigned)i * 32u);
   rt_prim q;
   __builtin_memcpy(&q, &v, sizeof(q));
   return q;
@@ -465,8 +466,8 @@ __device__ __forceinline__ void box_pair(const float* g, int k, bool lane_on, co
 template <bool STATS>
 __device__ __forceinline__ void box6_test(const ScanNode* __restrict__ scan, int node, int first, bool lane_on, const RayF& r, float t_min,
                                           float t_max, Hit& best, Counters& cnt) {
-  const u32x16 v0 = *(const RT_CONSTANT_AS u32x16*)(scan + node + 1);
-  const u32x2 v1 = *(const RT_CONSTANT_AS u32x2*)(scan + node + 2);
+  const u32x16 v0 = *(const RT_CONSTANT_AS u32x16*)((const RT_CONSTANT_AS char*)scan + (unsigned)node * 64u + 64u);
+  const u32x2 v1 = *(const RT_CONSTANT_AS u32x2*)((const RT_CONSTANT_AS char*)scan + (unsigned)node * 64u + 128u);
   float g[18];
   __builtin_memcpy(&g[0], &v0, 64);
   __builtin_memcpy(&g[16], &v1, 8);
