@@ -125,6 +125,8 @@ struct DevScene {
   rt_light light;
 };
 
+static_assert(sizeof(rt_prim) == 32 && sizeof(ScanNode) == 64, "record sizes the byte-offset loads assume");
+
 // The breadth-first node array as the stack traversal keeps it, 32 bytes per node:
 // the box (read for the root and for the root of an object's sub-tree) and, for a
 // leaf, left = ~ref (negative) and right = primitive count, 0 meaning objects[ref].
@@ -607,7 +609,7 @@ __device__ __forceinline__ void prim_list_lane(const DevScene& S, int first, int
   float loc_t = t_max;
   int loc_prim = -1;
   for (int qi = first; qi < first + count; ++qi) {
-    const rt_prim q = S.prims[qi];
+    const rt_prim q = *(const rt_prim*)((const char*)S.prims + ((unsigned)qi << 5));
     const int type = q.type & RT_PRIM_TYPE_MASK;
     float t = 0.0f;
     bool h;
@@ -676,7 +678,8 @@ __device__ __forceinline__ void trace_stack(const DevScene& S, unsigned* __restr
         continue;
       }
       // interior: both children's boxes from one 64-byte record
-      const float4* rec = (const float4*)&S.bnodes2[cur];
+      // base + 32-bit byte offset: the loads take the array's address from scalar registers and one shifted index per lane
+      const float4* rec = (const float4*)((const char*)S.bnodes2 + ((unsigned)cur << 6));
       const float4 llo = rec[0], lhi = rec[1], rlo = rec[2], rhi = rec[3];
       float tl, tr;
       const bool hl = slab_box_enter(llo, lhi, rlo.w, r, sg, t_min, t_max, best.t, tl);  // the spare words hold the children's y_top
@@ -1129,7 +1132,7 @@ __global__ void __launch_bounds__(64, (GENERAL != 0 || TRAV == TRAV_STACK) ? 5 :
     const bool hit = alive & (h.prim >= 0);
     DevPrim q;
     {
-      const float4* src = dprim_tab + 4 * (hit ? h.prim : 0);
+      const float4* src = (const float4*)((const char*)dprim_tab + ((unsigned)(hit ? h.prim : 0) << 6));
       const float4 q0 = src[0], q1 = src[1], q2 = src[2], q3 = src[3];
       __builtin_memcpy((char*)&q, &q0, 16);
       __builtin_memcpy((char*)&q + 16, &q1, 16);
