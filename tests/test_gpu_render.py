@@ -159,11 +159,11 @@ def test_render_degenerate_sizes_and_depths(gpu, orc, cornell):
 
 def test_render_sample_chunks_equal_separate_launches(gpu, cornell):
     """A launch that splits each tile's samples over several waves (chunks of at
-    least 32 samples, partial images added in a fixed order) gives what separate
-    launches over the same sample ranges give."""
+    least 32 samples, the last one in halving parts, partial images added in a
+    fixed order) gives what separate launches over the same sample ranges give."""
     gpu.upload_scene(cornell.flat)
     cam = cornell.camera
-    nx, ny, spp = 40, 24, 256  # 15 tiles: the launch uses 8 chunks of 32 samples
+    nx, ny, spp = 40, 24, 256  # 15 tiles: the launch uses 7 chunks of 32 samples and the last 32 as 16 + 8 + 8
     whole = gpu.render(cam, make_params(nx, ny, spp, seed=12))
     parts = sum(gpu.render(cam, make_params(nx, ny, 32, sample_begin=32 * k, seed=12)).astype(np.float64) for k in range(8))
     assert np.allclose(whole, parts, rtol=1e-5, atol=1e-5)
@@ -173,6 +173,20 @@ def test_render_sample_chunks_equal_separate_launches(gpu, cornell):
     b, b2 = gpu.render(cam, make_params(nx, ny, 40, sample_begin=60, seed=12), want_sumsq=True)
     assert np.allclose(s, a + b, rtol=1e-5, atol=1e-5)
     assert np.allclose(s2, a2 + b2, rtol=1e-5, atol=1e-4)
+
+
+def test_render_every_sample_index_runs_exactly_once(gpu, cornell):
+    """Sample counts around the sizes at which the last chunk is cut into parts:
+    the launch gives the sum of one-sample launches over the same indices."""
+    gpu.upload_scene(cornell.flat)
+    cam = cornell.camera
+    nx, ny = 24, 16
+    ones = [gpu.render(cam, make_params(nx, ny, 1, sample_begin=k, seed=21)).astype(np.float64) for k in range(131)]
+    for spp in (15, 16, 17, 31, 32, 40, 63, 64, 100, 131):
+        whole = gpu.render(cam, make_params(nx, ny, spp, seed=21))
+        assert np.allclose(whole, sum(ones[:spp]), rtol=1e-5, atol=1e-5), spp
+    shifted = gpu.render(cam, make_params(nx, ny, 40, sample_begin=70, seed=21))
+    assert np.allclose(shifted, sum(ones[70:110]), rtol=1e-5, atol=1e-5)
 
 
 def test_render_without_light_shape_uses_cosine_pdf_alone(gpu, orc, cornell):
