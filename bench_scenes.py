@@ -6,6 +6,13 @@ scene: Mpaths/s, Mrays/s, kernel ms, event counts.
   python bench_scenes.py --scene random --nx 400 --ny 225 --spp 16
   python bench_scenes.py --scene final --nx 1920 --ny 1080 --spp 64
   python bench_scenes.py --scene stress --spheres 1048576 --nx 3840 --ny 2160 --spp 4
+
+Several GPUs of one node (one process per GPU, as bench.py): pixel tiles or
+sample ranges per rank, one RCCL reduce(sum) of the fp32 buffers per image; the
+image and sample count stay fixed (strong scaling) and the line reports the job:
+
+  python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 bench_scenes.py \
+      --gpus 8 --shard tiles --scene final --nx 1920 --ny 1080 --spp 4096
 """
 import argparse
 import json
@@ -48,11 +55,28 @@ def main():
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--lbvh", action="store_true", help="rebuild the world tree on the device (rt_build_lbvh): a separate variant")
     ap.add_argument("--cpu-spp", type=int, default=0, help="also time the f64 oracle at this many spp (8 threads)")
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--shard", choices=("tiles", "samples"), default="tiles", help="how ranks split the image when --gpus > 1")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="ranks share GPU 0 and exchange host tensors over gloo: checks the multi-rank flow, not a benchmark")
     args = ap.parse_args()
 
     import torch
-    torch.cuda.set_device(0)  # torch first: it brings up the HIP runtime the library then shares
+    import torch.distributed as dist
+    n_ranks = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = 0 if args.rehearse_on_one_gpu else int(os.environ.get("LOCAL_RANK", "0"))
+    if n_ranks != args.gpus:
+        raise SystemExit("WORLD_SIZE=%d does not match --gpus %d (launch with torch.distributed.run)" % (n_ranks, args.gpus))
+    torch.cuda.set_device(local_rank)  # torch first: it brings up the HIP runtime the library then shares
+    if n_ranks > 1:
+        if args.rehearse_on_one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     from raytracing_amd import Renderer, Scene, make_params
+    from raytracing_amd.distributed import reduce_to_root, shard_params
+    from bench import VALU_PEAK_TFLOPS, HBM_PEAK_GBS, algorithmic_flops
     t0 = time.perf_counter()
     sc = Scene(0x5EED0000)
     with sc:
@@ -61,7 +85,7 @@ def main():
             sc.light_xz_rect(*light)
         flat = sc.flatten(world)
     t_build = time.perf_counter() - t0
-    r = Renderer(0)
+    r = Renderer(local_rank)
     t_lbvh = None
     if args.lbvh:
         r.build_lbvh(flat)  # first call pays for library initialisation
@@ -69,33 +93,82 @@ def main():
         flat = r.build_lbvh(flat)
         t_lbvh = time.perf_counter() - t1
     r.upload_scene(flat)
-    p = make_params(args.nx, args.ny, args.spp, sky=sky)
+    p = shard_params(make_params(args.nx, args.ny, args.spp, sky=sky), rank, n_ranks, args.shard)
     best = None
     for _ in range(args.reps):
         _, stats = r.render(cam, p, want_stats=True)
         if best is None or stats.kernel_ms < best.kernel_ms:
             best = stats
-    paths = args.nx * args.ny * args.spp
+    paths = args.nx * args.ny * args.spp  # of the whole job
     # the production build of the kernel (no event counters), device buffers, HIP events on the launch stream
-    dev = torch.device("cuda", 0)
+    dev = torch.device("cuda", local_rank)
     buf = torch.empty(args.ny * args.nx * 3, dtype=torch.float32, device=dev)
     stream = torch.cuda.current_stream(dev)
-    prod_ms = None
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if n_ranks > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    prod_ms = None   # this rank's kernel, best of the repetitions
+    job_ms = None    # kernel + exchange, slowest rank, best of the repetitions
     for _ in range(args.reps + 1):
+        fence()
+        t1 = time.perf_counter()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(stream)
         r.render_device(cam, p, buf.data_ptr(), None, stream.cuda_stream)
         e1.record(stream)
-        torch.cuda.synchronize(dev)
+        if n_ranks > 1:
+            if args.rehearse_on_one_gpu:
+                host = buf.cpu()
+                reduce_to_root(host)
+                buf.copy_(host)
+            else:
+                reduce_to_root(buf)
+        fence()
+        dt = time.perf_counter() - t1
+        if n_ranks > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
         ms = e0.elapsed_time(e1)
         prod_ms = ms if prod_ms is None else min(prod_ms, ms)
+        job_ms = dt * 1e3 if job_ms is None else min(job_ms, dt * 1e3)
+    # totals over the ranks of the event counts (each rank counted its own share)
+    rays, node_tests, flops = float(best.rays), float(best.node_tests), float(algorithmic_flops(best))
+    sphere_tests = float(best.sphere_tests)
+    if n_ranks > 1:
+        t = torch.tensor([rays, node_tests, flops, sphere_tests], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        rays, node_tests, flops, sphere_tests = (float(x) for x in t.tolist())
+    if rank != 0:
+        r.close()
+        if n_ranks > 1:
+            dist.destroy_process_group()
+        return
+    t_ms = prod_ms if n_ranks == 1 else job_ms
+    # Roofline of what the kernel itself evaluated (its event counters x the per-event constants of bench.py); for the
+    # sphere stress scene also the algorithmic bytes of its node and sphere fetches against the HBM peak.
+    roofline = {"bound": "valu", "achieved": round(flops / (t_ms * 1e-3) / 1e12, 3), "peak": VALU_PEAK_TFLOPS * n_ranks, "unit": "TFLOP/s"}
+    roofline["frac"] = round(roofline["achieved"] / roofline["peak"], 4)
+    if args.scene == "stress":
+        bytes_ = 32.0 * node_tests + 20.0 * sphere_tests
+        gbs = bytes_ / (t_ms * 1e-3) / 1e9
+        roofline["memory"] = {"algorithmic_GB/s": round(gbs, 1), "peak": HBM_PEAK_GBS * n_ranks, "frac": round(gbs / (HBM_PEAK_GBS * n_ranks), 4),
+                              "note": "32 B per box test + 20 B per sphere test; measured fabric traffic is in profiles/"}
     line = {
         "scene": args.scene, "nx": args.nx, "ny": args.ny, "spp": args.spp, "nodes": flat.n_nodes, "prims": flat.n_prims,
         "tree": "device LBVH (variant)" if args.lbvh else "reference median split", "lbvh_build_s": None if t_lbvh is None else round(t_lbvh, 4),
         "build_s": round(t_build, 2), "kernel_ms": round(prod_ms, 3), "counting_kernel_ms": round(best.kernel_ms, 3),
-        "Mpaths_per_s": round(paths / prod_ms / 1e3, 2), "Mrays_per_s": round(best.rays / prod_ms / 1e3, 2),
-        "rays_per_path": round(best.rays / float(paths), 3), "node_tests_per_ray": round(best.node_tests / float(best.rays), 2),
-        "note": "kernel_ms times the production build; the event counts come from a separate launch of the counting build",
+        "n_gpus": n_ranks, "sharding": "single GPU" if n_ranks == 1 else ("REHEARSAL on one GPU, " if args.rehearse_on_one_gpu else "") + args.shard,
+        "ms_per_image": round(t_ms, 3),
+        "Mpaths_per_s": round(paths / t_ms / 1e3, 2), "Mrays_per_s": round(rays / t_ms / 1e3, 2),
+        "rays_per_path": round(rays / float(paths), 3), "node_tests_per_ray": round(node_tests / rays, 2),
+        "roofline": roofline,
+        "note": "one GPU: the production kernel by HIP events; several: kernel + reduce, slowest rank, wall clock between barriers; "
+                "kernel_ms is rank 0's kernel; the event counts come from a separate launch of the counting build",
     }
     if args.cpu_spp > 0:
         from oracle import binding as orc
@@ -106,6 +179,8 @@ def main():
         line["cpu_oracle_Mpaths_per_s_8_threads"] = round(args.nx * args.ny * args.cpu_spp / dt / 1e6, 3)
     print(json.dumps(line))
     r.close()
+    if n_ranks > 1:
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -1,0 +1,11 @@
+#!/bin/bash
+# Multi-rank flow of bench_scenes.py on a one-GPU box (run through gpurun from the repository root): the ranks share GPU 0 and
+# exchange host tensors over gloo, so the numbers are not a benchmark; the image checks are.
+mkdir -p gpurun_out
+run() { timeout -k 10 200 "$@" 2>>gpurun_out/rehearse_scenes.err | grep '^{' >> gpurun_out/rehearse_scenes.jsonl || exit 1; }
+: > gpurun_out/rehearse_scenes.jsonl; : > gpurun_out/rehearse_scenes.err
+L="python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1"
+run python bench_scenes.py --scene final --nx 1920 --ny 1080 --spp 64
+run $L --master-port 29512 bench_scenes.py --gpus 2 --shard tiles --rehearse-on-one-gpu --scene final --nx 1920 --ny 1080 --spp 64
+run $L --master-port 29513 bench_scenes.py --gpus 2 --shard samples --rehearse-on-one-gpu --scene stress --spheres 65536 --nx 640 --ny 360 --spp 16
+cut -c1-700 gpurun_out/rehearse_scenes.jsonl
