@@ -114,11 +114,16 @@ def simple_light_scene(ratio):
     return camera, world
 
 
-def cornell_smoke_scene(ratio, smoke=True):
+def cornell_smoke_scene(ratio, smoke=True, flip_light=True):
     """src/scenes.rs:363-446 (commented out): the Cornell box with the larger,
-    dimmer, un-flipped light, a glass sphere with a mirror core, and, when
-    `smoke` is set, the ConstantMedium the commented lines at :413-418 describe
-    (density 0.01, grey, in a 150-radius sphere at the position of b2, :370)."""
+    dimmer light, a glass sphere with a mirror core, and, when `smoke` is set, the
+    ConstantMedium the commented lines at :413-418 describe (density 0.01, grey,
+    in a 150-radius sphere at the position of b2, :370).  The commented source has
+    the light un-flipped (:392); it predates DiffuseLight emitting only towards the
+    side its normal points to (material.rs:197-203), under which an un-flipped
+    ceiling light shines upwards and the box stays black.  flip_light=False gives
+    the scene as written, the default turns the light to face down as the live
+    cornell_box_scene does (:290-297)."""
     red = Lambertian.new(Texture.new_constant(vec3(0.65, 0.05, 0.05)))
     white = Lambertian.new(Texture.new_constant(vec3(0.73, 0.73, 0.73)))
     green = Lambertian.new(Texture.new_constant(vec3(0.12, 0.45, 0.15)))
@@ -126,7 +131,7 @@ def cornell_smoke_scene(ratio, smoke=True):
     items = [
         FlipNormals.new_yz(YZRect.new(0.0, 555.0, 0.0, 565.0, 555.0, green)),
         YZRect.new(0.0, 555.0, 0.0, 555.0, 0.0, red),
-        XZRect.new(113.0, 443.0, 127.0, 432.0, 554.0, light),
+        FlipNormals.new_xz(XZRect.new(113.0, 443.0, 127.0, 432.0, 554.0, light)) if flip_light else XZRect.new(113.0, 443.0, 127.0, 432.0, 554.0, light),
         FlipNormals.new_xz(XZRect.new(0.0, 555.0, 0.0, 555.0, 555.0, white)),
         XZRect.new(0.0, 555.0, 0.0, 555.0, 0.0, white),
         FlipNormals.new_xy(XYRect.new(0.0, 555.0, 0.0, 555.0, 555.0, white)),
@@ -165,7 +170,9 @@ def final_scene(ratio, seed=0x5EED0002, boxes_per_side=20, cluster=1000):
             y1 = 100.0 * (rng.random() + 0.01)
             boxes.append(Cuboid.new(vec3(x0, 0.0, z0), vec3(x0 + w, y1, z0 + w), ground))
     items = [BvhNode.new(boxes)]
-    items.append(XZRect.new(123.0, 423.0, 147.0, 412.0, 554.0, DiffuseLight.new(Texture.new_constant(scalar(7.0)))))
+    # DiffuseLight emits towards the side its normal points to (material.rs:197-203), so a ceiling light is flipped to face
+    # down, as the reference's Cornell box does (scenes.rs:290-297)
+    items.append(FlipNormals.new_xz(XZRect.new(123.0, 423.0, 147.0, 412.0, 554.0, DiffuseLight.new(Texture.new_constant(scalar(7.0))))))
     items.append(Sphere.new(vec3(400.0, 400.0, 200.0), 50.0, Lambertian.new_from_color(vec3(0.7, 0.3, 0.1))))
     items.append(Sphere.new(vec3(260.0, 150.0, 45.0), 50.0, Dielectric.new(1.5)))
     items.append(Sphere.new(vec3(0.0, 150.0, 145.0), 50.0, Metal.new(vec3(0.8, 0.8, 0.9), 10.0)))
@@ -198,7 +205,7 @@ def sphere_stress_scene(ratio, n_spheres=1 << 20, seed=0x5EED0003):
             for _ in range(16)]
     items = [Sphere.new(vec3(side * rng.random(), side * rng.random(), side * rng.random()), r * (0.5 + rng.random()),
                         mats[k & 15]) for k in range(n_spheres)]
-    items.append(XZRect.new(200.0, 800.0, 200.0, 800.0, 1100.0, DiffuseLight.new(Texture.new_constant(scalar(10.0)))))
+    items.append(FlipNormals.new_xz(XZRect.new(200.0, 800.0, 200.0, 800.0, 1100.0, DiffuseLight.new(Texture.new_constant(scalar(10.0))))))  # faces down
     world = HitableList.new(items)
     camera = Camera.new(vec3(500.0, 500.0, -1400.0), vec3(500.0, 500.0, 500.0), vec3(0.0, 1.0, 0.0), 40.0, ratio, 0.0, 10.0)
     return camera, world

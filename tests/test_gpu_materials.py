@@ -173,3 +173,24 @@ def test_long_primitive_list_render(gpu, orc):
         flat = sc.flatten(S.HitableList.new(world0.list[:6] + [blinds]))
         assert flat.n_prims > 64
         _compare(gpu, orc, flat, cam, 48, 48, 64, same_frac=0.9)
+
+
+@pytest.mark.parametrize("name", ["random", "final", "stress"])
+def test_named_scene_builders_render_like_the_oracle(gpu, orc, name):
+    """The builders behind the other named configurations (Book-1 random spheres,
+    the Book-2 final scene with its box grid, sphere cluster, marble, glass and two
+    media, and the sphere stress scene at 4096 spheres), at thumbnail size: same
+    seed against the fp32 oracle, other seed against the f64 oracle."""
+    ratio = 1.5
+    with Scene(31) as sc:
+        if name == "random":
+            cam, world = scenes.random_scene(ratio)
+        elif name == "final":
+            cam, world = scenes.final_scene(ratio)
+            sc.light_xz_rect(*scenes.FINAL_LIGHT_SHAPE)
+        else:
+            cam, world = scenes.sphere_stress_scene(ratio, 4096)
+            sc.light_xz_rect(*scenes.STRESS_LIGHT_SHAPE)
+        flat = sc.flatten(world)
+        assert flat.n_nodes > 64
+        _compare(gpu, orc, flat, cam, 60, 40, 64, same_frac=0.75, energy_tol=0.05)
