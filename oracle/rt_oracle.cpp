@@ -244,6 +244,19 @@ template <class P> struct World {
         if (temp < t_max && temp > t_min) {
           rec.t = temp;
           rec.p = r.point_at_parameter(rec.t);
+          if (sizeof(R) == 4) {
+            // fp32 only, not in the reference: ray(t) lies off the sphere by the rounding of t * d (1e-4 at a
+            // few thousand units), enough for the next ray to hit the same sphere again from inside; in f64
+            // that never shows.  The point is put back at distance |radius| from the centre.
+            const Vec dd = rec.p - center;
+            const R len = std::sqrt(dot<P>(dd, dd));
+            if (P::fused) {
+              const R scale = std::fabs(radius) * (R(1) / len);
+              rec.p = Vec(std::fma(dd.x, scale, center.x), std::fma(dd.y, scale, center.y), std::fma(dd.z, scale, center.z));
+            } else {
+              rec.p = center + dd * scalar<R>(std::fabs(radius) / len);
+            }
+          }
           get_sphere_uv(rec.p, rec.u, rec.v);
           if (P::fused) rec.normal = (rec.p - center) * scalar<R>(R(1) / radius);
           else rec.normal = (rec.p - center) / scalar<R>(radius);

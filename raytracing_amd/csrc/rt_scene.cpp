@@ -361,6 +361,18 @@ struct Flattener {
     node->right = 0;
   }
 
+  // The largest float not above v / the smallest not below v.
+  static float float_below(double v) {
+    float f = (float)v;
+    if ((double)f > v) f = std::nextafter(f, -INFINITY);
+    return f;
+  }
+  static float float_above(double v) {
+    float f = (float)v;
+    if ((double)f < v) f = std::nextafter(f, INFINITY);
+    return f;
+  }
+
   // Breadth-first emission of one tree; returns the index of its root.
   int emit_tree(const BvhNode* root, bool allow_objects) {
     std::deque<std::pair<const BvhNode*, int> > queue;
@@ -373,8 +385,10 @@ struct Flattener {
       queue.pop_front();
       rt_node node;
       std::memset(&node, 0, sizeof(node));
-      node.bmin[0] = (float)n->boxy.min.x; node.bmin[1] = (float)n->boxy.min.y; node.bmin[2] = (float)n->boxy.min.z;
-      node.bmax[0] = (float)n->boxy.max.x; node.bmax[1] = (float)n->boxy.max.y; node.bmax[2] = (float)n->boxy.max.z;
+      // The f64 box goes to fp32 rounded outwards, so the fp32 box contains it: rounded to nearest, the 0.0001 a rect's box
+      // is padded with (hitable.rs:185-190) disappears from |k| = 2048 on and the slab test rejects the zero-width box.
+      node.bmin[0] = float_below(n->boxy.min.x); node.bmin[1] = float_below(n->boxy.min.y); node.bmin[2] = float_below(n->boxy.min.z);
+      node.bmax[0] = float_above(n->boxy.max.x); node.bmax[1] = float_above(n->boxy.max.y); node.bmax[2] = float_above(n->boxy.max.z);
       if (n->contents) {
         emit_leaf(n->contents.get(), allow_objects, &node);
       } else {

@@ -197,7 +197,7 @@ FINAL_LIGHT_SHAPE = (123.0, 423.0, 147.0, 412.0, 554.0)
 def sphere_stress_scene(ratio, n_spheres=1 << 20, seed=0x5EED0003):
     """Traversal stress scene (no counterpart in the reference): n_spheres
     Lambertian spheres with centres uniform in a 1000-unit cube and radii small
-    enough that they rarely overlap, under one rect light."""
+    enough that they rarely overlap, under one large rect light high above."""
     rng = _random.Random(seed)
     side = 1000.0
     r = 0.25 * side / (n_spheres ** (1.0 / 3.0))
@@ -205,10 +205,11 @@ def sphere_stress_scene(ratio, n_spheres=1 << 20, seed=0x5EED0003):
             for _ in range(16)]
     items = [Sphere.new(vec3(side * rng.random(), side * rng.random(), side * rng.random()), r * (0.5 + rng.random()),
                         mats[k & 15]) for k in range(n_spheres)]
-    items.append(FlipNormals.new_xz(XZRect.new(200.0, 800.0, 200.0, 800.0, 1100.0, DiffuseLight.new(Texture.new_constant(scalar(10.0))))))  # faces down
+    items.append(FlipNormals.new_xz(XZRect.new(-500.0, 1500.0, -500.0, 1500.0, 3000.0, DiffuseLight.new(Texture.new_constant(scalar(10.0))))))  # faces down
     world = HitableList.new(items)
-    camera = Camera.new(vec3(500.0, 500.0, -1400.0), vec3(500.0, 500.0, 500.0), vec3(0.0, 1.0, 0.0), 40.0, ratio, 0.0, 10.0)
+    # from above the front edge, so the view is of the faces the light reaches (the cloud is opaque a few layers in)
+    camera = Camera.new(vec3(500.0, 1900.0, -1300.0), vec3(500.0, 500.0, 500.0), vec3(0.0, 1.0, 0.0), 40.0, ratio, 0.0, 10.0)
     return camera, world
 
 
-STRESS_LIGHT_SHAPE = (200.0, 800.0, 200.0, 800.0, 1100.0)
+STRESS_LIGHT_SHAPE = (-500.0, 1500.0, -500.0, 1500.0, 3000.0)

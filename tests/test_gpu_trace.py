@@ -272,3 +272,31 @@ def test_lbvh_on_small_and_degenerate_worlds(gpu, orc, cornell):
         gpu.upload_scene(one)
         prim, t = gpu.trace_closest(np.array([[0, 0, -5]], np.float32), np.array([[0, 0, 1]], np.float32))
         assert prim[0] == 0 and abs(t[0] - 4.0) < 1e-5
+
+
+def test_trace_rects_far_from_the_origin(gpu, orc):
+    """Rects at coordinates where fp32 cannot hold a box's 0.0001 padding (|k| >=
+    2048): the node boxes are rounded outwards on the host, so the tree finds them;
+    device = fp32 oracle bit for bit, = f64 oracle in primitive."""
+    from raytracing_amd import Scene
+    from raytracing_amd import scene as S
+    rng = np.random.RandomState(4)
+    ks = [554.0, 2048.0, 3000.0, 1.0e5, -7777.0]
+    with Scene(9) as sc:
+        white = S.Lambertian.new_from_color(S.vec3(0.7, 0.7, 0.7))
+        rects = [S.XZRect.new(-50.0, 50.0, -50.0, 50.0, k, white) for k in ks]
+        rects += [S.Sphere.new(S.vec3(float(x), 100.0, 0.0), 20.0, white) for x in range(-2000, 2001, 100)]  # makes the tree deep enough for the stack kernel
+        flat = sc.flatten(S.HitableList.new([S.BvhNode.new(rects)]))
+    gpu.upload_scene(flat)
+    n = 4000
+    k = np.asarray(ks)[rng.randint(0, len(ks), n)]
+    target = np.stack([rng.uniform(-60, 60, n), k, rng.uniform(-60, 60, n)], axis=1)
+    o = np.stack([rng.uniform(-200, 200, n), k - np.sign(k) * rng.uniform(5, 500, n), rng.uniform(-200, 200, n)], axis=1).astype(np.float32)
+    d = (target - o).astype(np.float32)
+    prim, t = gpu.trace_closest(o, d)
+    op, ot = orc.trace_closest(flat, o, d, mode=orc.ORC_F32_FUSED)
+    assert np.array_equal(prim, op) and np.array_equal(t, ot.astype(np.float32))
+    p64, _ = orc.trace_closest(flat, o, d, mode=orc.ORC_F64)
+    assert (prim == p64).mean() > 0.999
+    inside = (np.abs(target[:, 0]) < 49) & (np.abs(target[:, 2]) < 49)
+    assert (prim[inside] >= 0).all()

@@ -218,3 +218,32 @@ def test_cpp_host_program_fails_loudly_without_a_device(tmp_path):
     assert "no HIP device" in run.stderr
     assert not os.path.exists(out)
     assert subprocess.run([exe, "0"], capture_output=True, text=True, timeout=60).returncode == 2
+
+
+def test_rect_boxes_keep_their_thickness_at_large_coordinates():
+    """A rect's box is padded by 0.0001 (hitable.rs:185-190); in fp32 that is below
+    half a unit in the last place from |k| = 2048 on.  The f64 box is rounded
+    outwards on its way to the fp32 node array, so the box never collapses and the
+    tree still finds the rect (BVH walk = list walk, fp32 and f64)."""
+    from oracle import binding as orc
+    ks = [554.0, 2048.0, 3000.0, 1.0e5, -7777.0]
+    with Scene(9) as sc:
+        white = S.Lambertian.new_from_color(S.vec3(0.7, 0.7, 0.7))
+        rects = [S.XZRect.new(-50.0, 50.0, -50.0, 50.0, k, white) for k in ks]
+        rects += [S.XYRect.new(-50.0, 50.0, -50.0, 50.0, 4096.5, white), S.YZRect.new(-50.0, 50.0, -50.0, 50.0, -65536.25, white)]
+        flat = sc.flatten(S.HitableList.new([S.BvhNode.new(rects)]))
+    for i in range(flat.n_nodes):
+        n = flat.nodes[i]
+        assert all(n.bmax[c] > n.bmin[c] for c in range(3)), i
+    o = np.zeros((len(ks) + 2, 3), dtype=np.float32)
+    d = np.zeros_like(o)
+    for i, k in enumerate(ks):
+        o[i] = (3.0, k - 10.0 * np.sign(k), -4.0)
+        d[i] = (0.01, np.sign(k), 0.02)
+    o[-2] = (1.0, 2.0, 4000.0); d[-2] = (0.0, 0.01, 1.0)
+    o[-1] = (-65000.0, 2.0, 1.0); d[-1] = (-1.0, 0.01, 0.0)
+    for mode in (orc.ORC_F64, orc.ORC_F32):
+        pb, tb = orc.trace_closest(flat, o, d, mode=mode, traversal=orc.ORC_TRAVERSE_BVH)
+        pl, tl = orc.trace_closest(flat, o, d, mode=mode, traversal=orc.ORC_TRAVERSE_LIST)
+        assert (pl >= 0).all()
+        assert np.array_equal(pb, pl) and np.array_equal(tb, tl)
