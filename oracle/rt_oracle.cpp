@@ -172,8 +172,13 @@ template <class P> struct World {
       if (inv_d < R(0)) { R tmp = t0; t0 = t1; t1 = tmp; }
       t_min = t0 > t_min ? t0 : t_min;
       t_max = t1 < t_max ? t1 : t_max;
-      if (t_max <= t_min) return false;
+      if (sizeof(R) == 8 && t_max <= t_min) return false;
     }
+    // fp32 only, not in the reference: a rect's box is 0.0002 thick, and from an origin a few thousand units away
+    // (bound - origin) rounds to the same float for both faces, so t0 == t1 and the reference's `<=` rejects a box the
+    // ray goes through (in f64 that needs distances of 1e12).  The exit distance is widened by two units in the last
+    // place, which never rejects a box the exact test accepts.
+    if (sizeof(R) == 4) return !(t_max * R(1.00000024f) <= t_min);
     return true;
   }
 

@@ -349,7 +349,11 @@ __device__ __forceinline__ bool slab_core(float x0, float y0, float z0, float x1
   t_enter = t_min;
   const float ny_top = sg.y ? (y_top - r.o.y) * r.inv.y : ny;
   const float t_prune = fmaxf(fmaxf(nx, nz), fmaxf(ny_top, t_min0));
-  return !(t_max <= t_min) & !(t_prune > best_t);
+  // Not in the reference, which works in f64: a rect's box is 0.0002 thick, and from an origin a few thousand
+  // units away (bound - origin) rounds to the same float for both faces, so the entry and exit distances are
+  // equal and bvh.rs:58's `<=` rejects a box the ray goes through.  The exit distance is widened by two units
+  // in the last place, which never rejects a box the exact test accepts.
+  return !(t_max * 1.00000024f <= t_min) & !(t_prune > best_t);
 }
 // Without pruning (best_t = +inf) y_top plays no part.
 __device__ __forceinline__ bool slab_box(float x0, float y0, float z0, float x1, float y1, float z1, const RayF& r, const Signs& sg,

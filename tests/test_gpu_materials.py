@@ -194,3 +194,23 @@ def test_named_scene_builders_render_like_the_oracle(gpu, orc, name):
         flat = sc.flatten(world)
         assert flat.n_nodes > 64
         _compare(gpu, orc, flat, cam, 60, 40, 64, same_frac=0.75, energy_tol=0.05)
+
+
+def test_room_ten_times_the_cornell_box(gpu, orc):
+    """Every length of the Cornell box times ten (walls at 5550): the scale at which
+    fp32 loses a rect's 0.0002-thick box unless the slab test allows for it.  Trace
+    bit-exact against the fp32 oracle, image against the f64 one."""
+    from test_scene_host import _scaled_cornell
+    with Scene(41) as sc:
+        cam, world = _scaled_cornell(sc, 10.0)
+        flat = sc.flatten(world)
+    gpu.upload_scene(flat)
+    rng = np.random.RandomState(2)
+    n = 30000
+    o = rng.uniform(500.0, 5000.0, (n, 3)).astype(np.float32)
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    prim, t = gpu.trace_closest(o, d)
+    op, ot = orc.trace_closest(flat, o, d, mode=orc.ORC_F32_FUSED)
+    assert np.array_equal(prim, op) and np.array_equal(t, ot.astype(np.float32))
+    assert (prim >= 0).mean() > 0.85
+    _compare(gpu, orc, flat, cam, 48, 48, 128, same_frac=0.9)
