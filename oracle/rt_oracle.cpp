@@ -353,7 +353,11 @@ template <class P> struct World {
     boundary.kind = RT_OBJ_LIST;
     HitRecord<R> rec1, rec2;
     if (!xform_hit(boundary, r, -real_max(), real_max(), smp, depth, rec1)) return false;
-    if (!xform_hit(boundary, r, rec1.t + R(0.0001), real_max(), smp, depth, rec2)) return false;
+    R t_next = rec1.t + R(0.0001);
+    // fp32 only, not in the reference: beyond t = 2048 the 0.0001 is less than half a unit in the last place, the
+    // second search would start at rec1.t itself and a rect (whose test accepts t == t_min) would be found again
+    if (sizeof(R) == 4 && !(t_next > rec1.t)) t_next = std::nextafter(rec1.t, std::numeric_limits<R>::infinity());
+    if (!xform_hit(boundary, r, t_next, real_max(), smp, depth, rec2)) return false;
     if (rec1.t < t_min) rec1.t = t_min;
     if (rec2.t > t_max) rec2.t = t_max;
     if (rec1.t >= rec2.t) return false;

@@ -575,8 +575,17 @@ __device__ __forceinline__ void scan_range(const DevScene& S, int begin, int end
         if (box6) box6_test<STATS>(S.scan, i, n.a, on, q, -3.402823466e+38f, 3.402823466e+38f, b1, cnt);
         else list_test<STATS>(S.prims, n.a, n.b & 0x7fffff, on, q, -3.402823466e+38f, 3.402823466e+38f, b1, cnt);
         b2.t = 3.402823466e+38f; b2.prim = -1;
-        if (box6) box6_test<STATS>(S.scan, i, n.a, on, q, b1.t + 0.0001f, 3.402823466e+38f, b2, cnt);
-        else list_test<STATS>(S.prims, n.a, n.b & 0x7fffff, on, q, b1.t + 0.0001f, 3.402823466e+38f, b2, cnt);
+        // hitable.rs:566 searches on from rec1.t + 0.0001.  Not in the reference, which works in f64: beyond t = 2048 that
+        // sum is rec1.t itself in fp32 and a rect (whose test accepts t == t_min) would be found again, so the search
+        // starts at the next float above rec1.t at least.
+        float t_next = b1.t + 0.0001f;
+        {
+          const int bits = __float_as_int(b1.t);
+          const float up = __int_as_float(bits >= 0 ? bits + 1 : (bits == (int)0x80000000 ? 1 : bits - 1));
+          t_next = t_next > b1.t ? t_next : up;
+        }
+        if (box6) box6_test<STATS>(S.scan, i, n.a, on, q, t_next, 3.402823466e+38f, b2, cnt);
+        else list_test<STATS>(S.prims, n.a, n.b & 0x7fffff, on, q, t_next, 3.402823466e+38f, b2, cnt);
         float t1 = b1.t, t2 = b2.t;
         t1 = t1 < t_min ? t_min : t1;
         t2 = t2 > t_max ? t_max : t2;

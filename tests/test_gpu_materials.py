@@ -214,3 +214,23 @@ def test_room_ten_times_the_cornell_box(gpu, orc):
     assert np.array_equal(prim, op) and np.array_equal(t, ot.astype(np.float32))
     assert (prim >= 0).mean() > 0.85
     _compare(gpu, orc, flat, cam, 48, 48, 128, same_frac=0.9)
+
+
+def test_medium_in_a_box_of_the_ten_times_room(gpu, orc):
+    """The room of the previous test with its tall box turned into a ConstantMedium
+    (density scaled down by ten): boundary distances beyond 2048, where fp32 cannot
+    add hitable.rs:566's 0.0001 to the first boundary hit.  The second search starts
+    one float further at least; fp32 then sees the medium as often as f64 does."""
+    from test_scene_host import _scaled_cornell
+    with Scene(43) as sc:
+        cam, world0 = _scaled_cornell(sc, 10.0)
+        white = S.Lambertian.new_from_color(S.vec3(0.73, 0.73, 0.73))
+        box = S.Translate.new(S.RotateY.new(S.Cuboid.new(S.scalar(0.0), S.vec3(1650.0, 3300.0, 1650.0), white), 15.0),
+                              S.vec3(2650.0, 0.0, 2950.0))
+        items = world0.list[:6] + [S.ConstantMedium.new(box, 0.001, S.Texture.new_constant(S.scalar(0.9)))]
+        flat = sc.flatten(S.HitableList.new(items))
+    p = make_params(48, 48, 64, seed=5)
+    _, st32 = orc.render(flat, cam.c, p, mode=orc.ORC_F32_FUSED, want_sumsq=False, want_stats=True)
+    _, st64 = orc.render(flat, cam.c, p, mode=orc.ORC_F64, want_sumsq=False, want_stats=True)
+    assert abs(st32.hits - st64.hits) < 0.003 * st64.hits, (st32.hits, st64.hits)
+    _compare(gpu, orc, flat, cam, 48, 48, 64, same_frac=0.8)
