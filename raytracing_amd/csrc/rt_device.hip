@@ -949,6 +949,7 @@ struct RenderArgs {
   int nx, ny, spp, sample_begin, max_depth, sky;
   float t_min, inv_nx, inv_ny;
   int shard_index, shard_count;
+  int n_tiles;  // tiles this launch works on: all of them, or 64 per 64x64-pixel block of this shard
   unsigned key0, key1;
   int tiles_x, tiles_y;
   int n_chunks, chunk_spp;  // the samples of a tile are split into n_chunks work items of chunk_spp samples,
@@ -1015,7 +1016,7 @@ __global__ void __launch_bounds__(64, (GENERAL != 0 || TRAV == TRAV_STACK) ? 5 :
   // take items from a counter until none are left: workgroups are handed to the
   // shader engines in equal numbers although the engines do not have equal numbers
   // of CUs, so a launch of one workgroup per item leaves the larger engines waiting.
-  const int n_tiles = A.tiles_x * A.tiles_y;
+  const int n_tiles = A.n_tiles;
   const int n_items = n_tiles * A.n_chunks;
   // The kernel's arguments arrive as sixteen-register loads, and a value used from one
   // keeps all sixteen alive (and spilled and reloaded together) for the life of the
@@ -1030,15 +1031,20 @@ __global__ void __launch_bounds__(64, (GENERAL != 0 || TRAV == TRAV_STACK) ? 5 :
   if (item >= n_items) break;
   const int chunk = item / n_tiles;
   const int tile = item - chunk * n_tiles;
-  const int tx = tile % A.tiles_x, ty = tile / A.tiles_x;
+  int tx = tile % A.tiles_x, ty = tile / A.tiles_x;
+  bool mine = true;
+  if (A.shard_count > 1) {
+    // A shard's launch runs over its own 64x64-pixel blocks only (block b belongs to shard b % shard_count): 64 tiles
+    // per block, those beyond the image's edge empty.  The host has zeroed the output, so other shards' pixels stay 0.
+    const int blocks_x = (A.nx + 63) / 64;
+    const int block = A.shard_index + (tile >> 6) * A.shard_count;
+    tx = (block % blocks_x) * 8 + (tile & 7);
+    ty = (block / blocks_x) * 8 + ((tile >> 3) & 7);
+    mine = (tx < A.tiles_x) & (ty < A.tiles_y);
+  }
   const size_t slab = (size_t)chunk * A.nx * A.ny * 3;
   float* __restrict__ o_sum = out_sum + slab;
   float* __restrict__ o_sumsq = SUMSQ ? out_sumsq + slab : nullptr;
-  bool mine = true;
-  if (A.shard_count > 1) {
-    const int big = ((ty * 8) / 64) * ((A.nx + 63) / 64) + (tx * 8) / 64;
-    mine = big % A.shard_count == A.shard_index;
-  }
 #pragma unroll
   for (int c = 0; c < (SUMSQ ? 6 : 3); ++c) acc[wib][c][lane] = 0.0f;
 
@@ -1055,7 +1061,7 @@ __global__ void __launch_bounds__(64, (GENERAL != 0 || TRAV == TRAV_STACK) ? 5 :
     s_len = o1 - o0;
   }
   const int s_count = mine ? s_len : 0;
-  const int pool_size = 64 * s_count;  // a tile of another shard is written as zeros
+  const int pool_size = 64 * s_count;
   int pool_next = 0;
 
   // Per-lane path state.  A lane is either on a path (alive) or waiting for an
@@ -1814,7 +1820,18 @@ int launch_render(rt_ctx* ctx, const rt_camera* cam, const rt_render_params* p, 
   A.key0 = (unsigned)p->seed; A.key1 = (unsigned)(p->seed >> 32);
   A.tiles_x = (p->nx + 7) / 8; A.tiles_y = (p->ny + 7) / 8;
   const size_t n = (size_t)p->nx * p->ny * 3;
-  const int n_tiles = A.tiles_x * A.tiles_y;
+  int n_tiles = A.tiles_x * A.tiles_y;
+  if (p->shard_count > 1) {
+    const int n_blocks = ((p->nx + 63) / 64) * ((p->ny + 63) / 64);
+    const int mine = (n_blocks - p->shard_index + p->shard_count - 1) / p->shard_count;  // blocks b = shard_index (mod shard_count)
+    n_tiles = mine * 64;
+  }
+  A.n_tiles = n_tiles;
+  if (n_tiles == 0) {  // more shards than blocks: this one has nothing to render
+    HIP_TRY(hipMemsetAsync(d_sum, 0, n * sizeof(float), stream));
+    if (d_sumsq) HIP_TRY(hipMemsetAsync(d_sumsq, 0, n * sizeof(float), stream));
+    return RT_OK;
+  }
   // Load balance: a wave keeps its work item for its whole life, so the grid
   // needs many times more items than the chip has wave slots (256 CUs x ~24
   // waves) or the last round leaves most of the chip idle.  Split the samples
@@ -1874,6 +1891,11 @@ int launch_render(rt_ctx* ctx, const rt_camera* cam, const rt_render_params* p, 
   long long waves = 32LL * (ctx->n_cus > 0 ? ctx->n_cus : 1);
   if (waves > n_items) waves = n_items;
   HIP_TRY(hipMemsetAsync(ctx->d_queue, 0, sizeof(unsigned), stream));
+  if (p->shard_count > 1) {
+    // a shard writes its own tiles only: everything else in the image (or in every partial image) is zero
+    HIP_TRY(hipMemsetAsync(k_sum, 0, (size_t)A.n_chunks * n * sizeof(float), stream));
+    if (k_sumsq) HIP_TRY(hipMemsetAsync(k_sumsq, 0, (size_t)A.n_chunks * n * sizeof(float), stream));
+  }
   hipLaunchKernelGGL(fn, dim3((unsigned)waves), block, lds_bytes, stream, ctx->dev, dc, A, k_sum, k_sumsq, ctx->d_stats, ctx->d_queue);
   HIP_TRY(hipGetLastError());
   if (A.n_chunks > 1) {
