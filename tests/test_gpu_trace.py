@@ -300,3 +300,46 @@ def test_trace_rects_far_from_the_origin(gpu, orc):
     assert (prim == p64).mean() > 0.999
     inside = (np.abs(target[:, 0]) < 49) & (np.abs(target[:, 2]) < 49)
     assert (prim[inside] >= 0).all()
+
+
+def test_trace_degenerate_rays(gpu, orc, cornell):
+    """Rays the reference's arithmetic turns into NaN or infinity: direction
+    components exactly 0 with the origin exactly on a wall's plane (t = 0/0, which
+    passes XZRect::hit's rejects, hitable.rs:218-227), the zero direction, very
+    long and very short directions."""
+    gpu.upload_scene(cornell.flat)
+    rng = np.random.RandomState(11)
+    o, d = [], []
+    planes = [0.0, 555.0]
+    for axis in range(3):
+        for k in planes:
+            for _ in range(200):
+                p = rng.uniform(1.0, 554.0, 3)
+                p[axis] = k
+                v = rng.normal(size=3)
+                v[axis] = 0.0  # slides along the wall
+                o.append(p); d.append(v)
+                v2 = np.zeros(3); v2[(axis + 1) % 3] = rng.choice([-1.0, 1.0])  # along one axis only
+                o.append(p); d.append(v2)
+    for _ in range(300):
+        o.append(rng.uniform(1.0, 554.0, 3)); d.append(np.zeros(3))
+        o.append(rng.uniform(1.0, 554.0, 3)); d.append(rng.normal(size=3) * 1e-30)
+        o.append(rng.uniform(1.0, 554.0, 3)); d.append(rng.normal(size=3) * 1e30)
+        o.append(rng.uniform(1.0, 554.0, 3)); d.append(rng.normal(size=3) * 1e-38)
+    o = np.asarray(o, dtype=np.float32)
+    d = np.asarray(d, dtype=np.float32)
+    prim, t = gpu.trace_closest(o, d)
+    oprim, ot = orc.trace_closest(cornell.flat, o, d, mode=orc.ORC_F32_FUSED)
+    same = (prim == oprim) & ((t == ot.astype(np.float32)) | (np.isnan(t) & np.isnan(ot)))
+    n_plane = 3 * 2 * 200 * 2
+    cats = {"slide": same[0:n_plane:2], "axis": same[1:n_plane:2], "zero": same[n_plane + 0::4], "tiny": same[n_plane + 1::4],
+            "huge": same[n_plane + 2::4], "denormal": same[n_plane + 3::4]}
+    # Zero, denormal, tiny and huge directions give infinities the device reproduces bit for bit.
+    for k in ("zero", "tiny", "huge", "denormal"):
+        assert cats[k].all(), (k, float(cats[k].mean()))
+    # A ray lying exactly in a wall's plane makes t = 0/0.  The reference then carries NaN as its closest distance and what
+    # it returns depends on how each later comparison treats NaN; the device carries it differently (its range tests are
+    # medians) and agrees on about two thirds of such rays.  No path of a render produces one (a scattered direction never
+    # has a component that is exactly 0), so these are only required to come back, with a primitive the scene has.
+    assert ((prim >= -1) & (prim < cornell.flat.n_prims)).all()
+    assert cats["slide"].mean() > 0.5 and cats["axis"].mean() > 0.5
