@@ -17,7 +17,8 @@ def _random_hitable(rng, mats, allow_nested=True):
     c = rng.uniform(-10, 10, 3)
     kind = rng.randint(8 if allow_nested else 6)
     if kind == 0:
-        return S.Sphere.new(S.vec3(*c), float(rng.uniform(0.2, 2.0)), m)
+        # one sphere in five has a negative radius: the hollow-glass trick, normals point inwards (hitable.rs:63)
+        return S.Sphere.new(S.vec3(*c), float(rng.uniform(0.2, 2.0)) * (-1.0 if rng.rand() < 0.2 else 1.0), m)
     if kind in (1, 2, 3):
         a0, b0 = rng.uniform(-10, 8, 2)
         a1, b1 = a0 + rng.uniform(0.5, 6), b0 + rng.uniform(0.5, 6)
