@@ -291,3 +291,47 @@ def test_fp32_tree_walk_sees_thin_boxes_from_far_origins():
     p64, _ = orc.trace_closest(flat, o, d, mode=orc.ORC_F64)
     p32, _ = orc.trace_closest(flat, o, d, mode=orc.ORC_F32_FUSED)
     assert (p32 != p64).mean() < 2e-3, (p32 != p64).mean()
+
+
+def test_rust_declarations_in_the_integration_notes_follow_the_header():
+    """The `#[repr(C)]` structs a maintainer would paste from INTEGRATION.md list the
+    fields of include/rt_abi.h's structs in the same order with the same types, and
+    every `pub fn` there is a symbol the header declares."""
+    header = open(os.path.join(ROOT, "include", "rt_abi.h")).read() + open(os.path.join(ROOT, "include", "rt_scene_api.h")).read()
+    notes = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    header_nc = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    ctype = {"float": "f32", "double": "f64", "int32_t": "i32", "uint64_t": "u64", "int": "i32"}
+
+    def c_fields(name):
+        body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (name, name), header_nc, re.S).group(1)
+        out = []
+        for decl in body.split(";"):
+            decl = " ".join(decl.split())
+            if not decl:
+                continue
+            m = re.match(r"const (\w+)\* (\w+)$", decl)
+            if m:
+                out.append((m.group(2), "*const " + m.group(1)))
+                continue
+            ty, rest = decl.split(" ", 1)
+            for item in rest.split(","):
+                item = item.strip()
+                dims = re.findall(r"\[(\d+)\]", item)
+                t = ctype[ty]
+                for dim in reversed(dims):
+                    t = "[%s; %s]" % (t, dim)
+                out.append((re.sub(r"\[.*", "", item), t))
+        return out
+
+    def rust_fields(name):
+        body = re.search(r"pub struct %s\s*\{(.*?)\n?\}" % name, notes, re.S).group(1)
+        out = []
+        for m in re.finditer(r"pub (\w+): ((?:\[+[^,]*?\]+)|(?:\*const \w+)|\w+)\s*(?:,|$)", body.replace("\n", " ")):
+            out.append((m.group(1).rstrip("_") if m.group(1) == "type_" else m.group(1), m.group(2)))
+        return out
+
+    for name in ("rt_node", "rt_prim", "rt_object", "rt_material", "rt_texture", "rt_perlin", "rt_light", "rt_scene", "rt_camera",
+                 "rt_render_params", "rt_stats"):
+        assert rust_fields(name) == c_fields(name), (name, rust_fields(name), c_fields(name))
+    for fn in re.findall(r"pub fn (\w+)\(", notes):
+        assert re.search(r"\b%s\(" % fn, header_nc), fn
