@@ -1792,6 +1792,7 @@ int check_params(const rt_render_params* p) {
   if (!p) return rt::set_error(RT_ERR_INVALID, "params is null");
   if (p->nx <= 0 || p->ny <= 0 || p->nx > 32768 || p->ny > 32768) return rt::set_error(RT_ERR_INVALID, "image size out of range");
   if (p->spp <= 0 || p->spp > (1 << 24) || p->sample_begin < 0) return rt::set_error(RT_ERR_INVALID, "spp out of range (1 .. 2^24)");
+  if (p->sample_begin > 0x7fffffff - p->spp) return rt::set_error(RT_ERR_INVALID, "sample_begin + spp exceeds the 31-bit sample index");
   if (p->max_depth < 0 || p->max_depth > 1000) return rt::set_error(RT_ERR_INVALID, "max_depth out of range");
   if (!(p->t_min >= 0.0f) || !(p->t_min < 3.0e38f)) return rt::set_error(RT_ERR_INVALID, "t_min must be finite and not negative");
   if (p->sky != RT_SKY_BLACK && p->sky != RT_SKY_GRADIENT) return rt::set_error(RT_ERR_INVALID, "unknown sky mode");

@@ -136,7 +136,8 @@ def test_render_argument_errors(gpu, cornell):
     from raytracing_amd import RtError
     gpu.upload_scene(cornell.flat)
     for bad in (make_params(0, 8, 1), make_params(8, 8, 0), make_params(8, 8, 1, shard_index=2, shard_count=2),
-                make_params(8, 8, 1, sky=7), make_params(8, 8, 1, t_min=-1.0), make_params(8, 8, 1, t_min=float("inf"))):
+                make_params(8, 8, 1, sky=7), make_params(8, 8, 1, t_min=-1.0), make_params(8, 8, 1, t_min=float("inf")),
+                make_params(8, 8, 16, sample_begin=2**31 - 8)):
         with pytest.raises(RtError) as e:
             gpu.render(cornell.camera, bad)
         assert e.value.code == _lib.RT_ERR_INVALID
