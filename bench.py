@@ -55,6 +55,7 @@ def main():
     ap.add_argument("--cpu-spp", type=int, default=256, help="samples per pixel of the CPU baseline's bounded run")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stats", action="store_true")
+    ap.add_argument("--no-overlap", action="store_true", help="several ranks: wait for each image's reduce before rendering the next")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="N ranks share GPU 0 and exchange over gloo: checks the multi-rank control flow on a one-GPU box, not a benchmark")
     args = ap.parse_args()
@@ -93,25 +94,44 @@ def main():
     r.upload_scene(flat)
 
     # sample-range split: rank g renders samples [g*spp/N, (g+1)*spp/N) of every pixel
-    from raytracing_amd.distributed import reduce_to_root, shard_params
+    from raytracing_amd.distributed import shard_params
     params = shard_params(make_params(nx, ny, spp, seed=seed), rank, world, "samples")
-    buf = torch.empty(ny * nx * 3, dtype=torch.float32, device=dev)
+    # With several ranks, images alternate between two buffers and the reduce of one image runs (on RCCL's stream) while
+    # the next image renders; a buffer is rendered into again only after its reduce has been waited for.
+    overlap = world > 1 and not args.no_overlap
+    bufs = [torch.empty(ny * nx * 3, dtype=torch.float32, device=dev) for _ in range(2 if world > 1 else 1)]
+    pending = [None] * len(bufs)
     stream = torch.cuda.current_stream(dev)
+    state = {"images": 0}
+
+    def finish(slot):
+        if pending[slot] is not None:
+            work, t = pending[slot]
+            work.wait()  # RCCL: the current stream waits; gloo: the host does
+            if t is not bufs[slot]:
+                bufs[slot].copy_(t)
+            pending[slot] = None
 
     def step(ev0=None, ev1=None):
+        slot = state["images"] % len(bufs)
+        state["images"] += 1
+        buf = bufs[slot]
+        finish(slot)
         if ev0 is not None:
             ev0.record(stream)
         r.render_device(cam, params, buf.data_ptr(), None, stream.cuda_stream)
         if ev1 is not None:
             ev1.record(stream)
-        if args.rehearse_on_one_gpu and world > 1:
-            host = buf.cpu()  # gloo exchanges host tensors
-            reduce_to_root(host)
-            buf.copy_(host)
-        else:
-            reduce_to_root(buf)
+        if world > 1:
+            # gloo (the rehearsal) exchanges host tensors; RCCL reduces the device buffer in place
+            t = buf.cpu() if args.rehearse_on_one_gpu else buf
+            pending[slot] = (dist.reduce(t, dst=0, op=dist.ReduceOp.SUM, async_op=True), t)
+            if not overlap:
+                finish(slot)
 
     def fence():
+        for slot in range(len(bufs)):
+            finish(slot)
         torch.cuda.synchronize(dev)
         if world > 1:
             dist.barrier()
@@ -139,6 +159,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     kernel_ms = sum(a.elapsed_time(b) for a, b in events) / max(1, args.steps)
+    buf = bufs[(state["images"] - 1) % len(bufs)]  # the last image
     image_checksum = float(buf.double().sum().item()) if rank == 0 else 0.0
 
     # HBM bytes per launch of the dominant kernel from a committed PMC profile of this exact workload
@@ -224,7 +245,7 @@ def main():
             "config": {"workload": "cornell_box_scene (scenes.rs:276-360) %dx%d @ %d spp, MixturePDF light sampling, "
                                    "max depth 50" % (nx, ny, spp),
                        "sharding": ("REHEARSAL: ranks share one GPU, gloo exchange" if args.rehearse_on_one_gpu else
-                                    "sample range per GPU + RCCL reduce(sum) to rank 0") if world > 1 else "single GPU",
+                                    "sample range per GPU + RCCL reduce(sum) to rank 0" + (", overlapped with the next image's render" if overlap else "")) if world > 1 else "single GPU",
                        "seed": seed},
             "roofline": roofline,
             "cpu_baseline": cpu,
