@@ -281,3 +281,30 @@ def test_cpp_host_program_renders_the_same_image(gpu, tmp_path):
         img_py = gpu.tonemap(s, 16)
     assert img_cpp.shape == (200, 200, 3)
     assert np.array_equal(img_cpp, img_py)
+
+
+def test_render_against_the_stored_images(gpu, cornell):
+    """The device against tests/golden/oracle_vectors.npz: the f64 restatement's
+    24x24 Cornell image and 16x16 cornell_smoke image at 32 samples (sums and second
+    moments), compared with device renders of the same size from another seed by
+    the standard-error test; no oracle code runs here."""
+    import os
+    from conftest import GOLDEN
+    from raytracing_amd import Scene, scenes
+    v = np.load(os.path.join(GOLDEN, "oracle_vectors.npz"))
+    with Scene(0x5EED0001) as sc:
+        cam, world = scenes.cornell_smoke_scene(1.0)
+        sc.light_xz_rect(*scenes.SMOKE_LIGHT_SHAPE)
+        smoke = sc.flatten(world)
+        cases = [(cornell.flat, cornell.camera, 24, v["cornell_sum"], v["cornell_sumsq"]), (smoke, cam, 16, v["smoke_sum"], v["smoke_sumsq"])]
+        for flat, camera, n, want, want2 in cases:
+            gpu.upload_scene(flat)
+            spp = 32
+            s, s2 = gpu.render(camera, make_params(n, n, spp, seed=99), want_sumsq=True)
+            ma, mb, se, z = _z_scores(s.astype(np.float64), s2.astype(np.float64), want, want2, spp)
+            valid = se > 0
+            zz = z[valid]
+            assert valid.mean() > 0.6
+            assert (np.abs(zz) > 3.5).mean() < 0.02, (np.abs(zz) > 3.5).mean()
+            assert abs(zz.mean()) < 0.15, zz.mean()
+            assert abs(ma.mean() - mb.mean()) / mb.mean() < 0.08, (ma.mean(), mb.mean())

@@ -343,3 +343,21 @@ def test_trace_degenerate_rays(gpu, orc, cornell):
     # has a component that is exactly 0), so these are only required to come back, with a primitive the scene has.
     assert ((prim >= -1) & (prim < cornell.flat.n_prims)).all()
     assert cats["slide"].mean() > 0.5 and cats["axis"].mean() > 0.5
+
+
+def test_trace_against_the_stored_vectors(gpu, cornell):
+    """The device against tests/golden/oracle_vectors.npz (the f64 restatement's
+    nearest hits on 2048 fixed rays): same primitive, t within 1e-5 relative, on
+    the rays in general position; no oracle code runs in this test."""
+    import os
+    from conftest import GOLDEN
+    v = np.load(os.path.join(GOLDEN, "oracle_vectors.npz"))
+    gpu.upload_scene(cornell.flat)
+    prim, t = gpu.trace_closest(v["ray_o"], v["ray_d"])
+    n = len(prim)
+    n_generic = 2 * (n // 3) + n // 12
+    same = prim == v["ray_prim"]
+    assert same[:n_generic].mean() > 0.999, same[:n_generic].mean()
+    assert same.mean() > 0.98
+    hit = same & (v["ray_prim"] >= 0)
+    assert_t_close(t[hit].astype(np.float64), v["ray_t"][hit], v["ray_d"][hit])

@@ -110,3 +110,21 @@ def test_oracle_tonemap(orc):
     sums = np.array([[[0.0, 4.0, 1.0], [0.25 * 4, 100.0, float("nan")]]])
     img = orc.tonemap(sums, 4)
     assert img.tolist() == [[[0, 255, 127], [127, 255, 0]]]
+
+
+def test_restatement_reproduces_its_stored_vectors():
+    """tests/golden/oracle_vectors.npz holds the f64 restatement's outputs on fixed
+    inputs (made by tests/golden/make_oracle_vectors.py): the flattened Cornell box,
+    2048 nearest hits, two small images.  Recomputed here they must come out the
+    same, so a change to the restatement or the flattener cannot slip by.  (They pin
+    the restatement against itself; nothing of the reference's exists to pin it.)"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_oracle_vectors", os.path.join(GOLDEN, "make_oracle_vectors.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    now = mod.build()
+    want = np.load(os.path.join(GOLDEN, "oracle_vectors.npz"))
+    for k in ("nodes", "prims", "ray_o", "ray_d", "ray_prim"):
+        assert np.array_equal(now[k], want[k]), k
+    for k in ("ray_t", "ray_normal", "ray_p", "cornell_sum", "cornell_sumsq", "smoke_sum", "smoke_sumsq"):
+        assert np.allclose(now[k], want[k], rtol=1e-12, atol=0.0, equal_nan=True), k
