@@ -895,7 +895,8 @@ __device__ __forceinline__ float perlin_noise(const rt_perlin* __restrict__ pn, 
   const float vv = v * v * (3.0f - 2.0f * v);
   const float ww = w * w * (3.0f - 2.0f * w);
   float accum = 0.0f;
-#pragma unroll
+  // the outer loop stays a loop: eight corners' table reads in flight at once cost more registers than the function has
+#pragma unroll 1
   for (int di = 0; di < 2; ++di)
 #pragma unroll
     for (int dj = 0; dj < 2; ++dj)
@@ -1073,8 +1074,37 @@ __global__ void __launch_bounds__(64, (GENERAL != 0 || TRAV == TRAV_STACK) ? 5 :
   int pix = 0;            // pixel within the tile
   unsigned pixel_id = 0;  // j*nx + i
   unsigned sample = 0;
+  int pend = -1;          // GENERAL == 2: a colour still to come from Texture::value, material index << 1 | ended-on-a-light
 
   for (;;) {
+    if (GENERAL == 2 && S.textured) {
+      // ---- Texture::value of the previous vertex (texture.rs:22-35).  It is evaluated here, where only the path
+      // state is live, instead of in the middle of the shading code: Perlin turbulence is a call, and everything live
+      // across a call has to sit in the registers the callee preserves.  The vertex used colour (1,1,1); a path that
+      // went on gets its weight multiplied now, one that ended on a textured light adds its sample now. ----
+      if (__ballot(pend >= 0) != 0ull) {
+        if (pend >= 0) {
+          const F3 c = texture_value(S.textures, S.perlins, S.materials[pend >> 1].texture, ro);
+          const F3 v = f3(thr.x * c.x, thr.y * c.y, thr.z * c.z);
+          if (pend & 1) {
+            const float r = v.x != v.x ? 0.0f : v.x, g = v.y != v.y ? 0.0f : v.y, b = v.z != v.z ? 0.0f : v.z;  // de_nan
+            if (r != 0.0f || g != 0.0f || b != 0.0f) {
+              atomicAdd(&acc[wib][0][pix], r);
+              atomicAdd(&acc[wib][1][pix], g);
+              atomicAdd(&acc[wib][2][pix], b);
+              if (SUMSQ) {
+                atomicAdd(&acc[wib][3][pix], r * r);
+                atomicAdd(&acc[wib][4][pix], g * g);
+                atomicAdd(&acc[wib][5][pix], b * b);
+              }
+            }
+          } else {
+            thr = v;
+          }
+        }
+        pend = -1;
+      }
+    }
     // ---- hand (pixel, sample) items to the lanes without a path (main.rs:96-101):
     // ballot the idle lanes, rank them, take consecutive items from the pool ----
     const unsigned long long need = __ballot(!alive);
@@ -1170,10 +1200,9 @@ __global__ void __launch_bounds__(64, (GENERAL != 0 || TRAV == TRAV_STACK) ? 5 :
     const int mat_type = (q.flags >> DP_MAT_SHIFT) & 7;
     F3 color = f3(q.color[0], q.color[1], q.color[2]);
     if (STATS) cnt.hits += hit;
-    if (GENERAL == 2 && S.textured) {
-      // Texture::value for the lanes whose material has a checker or noise texture.
-      if (hit && (q.flags & DP_TEXTURED)) color = texture_value(S.textures, S.perlins, S.materials[q.flags >> DP_INDEX_SHIFT].texture, sf.p);
-    }
+    // A checker or noise texture's colour comes at the top of the next trip (see there); until then it counts as white.
+    const bool textured = GENERAL == 2 && S.textured && hit && (q.flags & DP_TEXTURED);
+    if (GENERAL == 2) color = sel3(textured, f3(1.0f, 1.0f, 1.0f), color);
 
     // material.rs:197-203: a light emits towards the side its normal points to and never scatters.
     const bool is_light = mat_type == RT_MAT_DIFFUSE_LIGHT;
@@ -1185,7 +1214,7 @@ __global__ void __launch_bounds__(64, (GENERAL != 0 || TRAV == TRAV_STACK) ? 5 :
       const float t = 0.5f * (ud.y + 1.0f);
       sky = f3((1.0f - t) + t * 0.5f, (1.0f - t) + t * 0.7f, (1.0f - t) + t * 1.0f);
     }
-    const F3 le = sel3(emits, color, sel3(hit, f3(0, 0, 0), sky));
+    const F3 le = sel3(emits, (GENERAL == 2) ? sel3(textured, f3(0, 0, 0), color) : color, sel3(hit, f3(0, 0, 0), sky));
     const F3 radiance = f3(thr.x * le.x, thr.y * le.y, thr.z * le.z);  // what this vertex adds to the sample, before de_nan
 
     // Lambertian under MixturePDF(HitablePDF(light), CosinePDF(normal)), main.rs:173-197.
@@ -1314,7 +1343,13 @@ __global__ void __launch_bounds__(64, (GENERAL != 0 || TRAV == TRAV_STACK) ? 5 :
     // the direction is kept clean (it feeds the reciprocals' range test meanwhile).
     ro = sf.p;
     rd = sel3(go_on, dir, rd);
-    thr = thr_next;
+    if (GENERAL == 2) {
+      const bool lit = textured & emits;  // its sample is thr * colour: the weight is kept for the top of the next trip
+      pend = (textured & (go_on | emits)) ? ((q.flags >> DP_INDEX_SHIFT) << 1) | (lit ? 1 : 0) : -1;
+      thr = sel3(lit, thr, thr_next);
+    } else {
+      thr = thr_next;
+    }
     depth += go_on ? 1 : 0;
     alive = go_on;
   }
