@@ -971,7 +971,7 @@ struct RenderArgs {
 // surfaces with constant textures and no media (the Cornell box); 1 adds Metal,
 // Dielectric, Isotropic and ConstantMedium; 2 adds checker and noise textures.
 template <bool STATS, bool SUMSQ, int TRAV, int GENERAL>
-__global__ void __launch_bounds__(64, (GENERAL != 0 || TRAV == TRAV_STACK) ? 5 : RT_RENDER_WAVES_PER_SIMD) render_kernel(DevScene S, DevCamera cam, RenderArgs A, float* __restrict__ out_sum,
+__global__ void __launch_bounds__(64, (TRAV == TRAV_STACK && GENERAL != 2) ? 6 : ((GENERAL != 0 || TRAV == TRAV_STACK) ? 5 : RT_RENDER_WAVES_PER_SIMD)) render_kernel(DevScene S, DevCamera cam, RenderArgs A, float* __restrict__ out_sum,
                                                      float* __restrict__ out_sumsq, unsigned long long* __restrict__ stats, unsigned* __restrict__ queue) {
   // Single-wave workgroups: every wave is on its own, none waits for the slowest
   // wave of a larger group.
