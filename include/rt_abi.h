@@ -250,7 +250,12 @@ int rt_render(rt_ctx* ctx, const rt_camera* cam, const rt_render_params* params,
 
 /* Same computation with device-resident outputs, enqueued on `hip_stream`
  * (a hipStream_t passed as void*; NULL is the default stream).  The buffers are
- * overwritten, not accumulated.  Returns after enqueueing. */
+ * overwritten, not accumulated.  Returns after enqueueing.  All launches of one
+ * context share its work counter and partial-image buffer, so they run one after
+ * the other: a launch on another stream than the context's previous launch first
+ * waits (on the device) for that launch to end.  To overlap renders, use one
+ * context per stream.  A launch that needs a larger partial-image buffer than any
+ * before it on this context allocates it during the call (which synchronises). */
 int rt_render_device(rt_ctx* ctx, const rt_camera* cam, const rt_render_params* params,
                      float* d_sum_rgb, float* d_sumsq_rgb_or_null, void* hip_stream);
 
@@ -266,6 +271,12 @@ int rt_trace_closest(rt_ctx* ctx, const float* o, const float* d, size_t n, floa
  * (255.99*c) truncated to u8.  sum_rgb and rgb8 are host buffers. */
 int rt_tonemap(rt_ctx* ctx, const float* sum_rgb, int32_t nx, int32_t ny, int32_t spp_total,
                uint8_t* rgb8);
+
+/* The same on device-resident buffers (the sums rt_render_device wrote; nx*ny*3
+ * bytes out), enqueued on `hip_stream`: render, tonemap and one copy of the 8-bit
+ * image to the host are then the whole of main.rs:67-155. */
+int rt_tonemap_device(rt_ctx* ctx, const float* d_sum_rgb, int32_t nx, int32_t ny, int32_t spp_total,
+                      uint8_t* d_rgb8, void* hip_stream);
 
 /* An alternative to BvhNode::new (src/bvh.rs:105-147) for the world tree, built on
  * the device: a linear BVH (Morton order of the leaf-box centres, hierarchy from the

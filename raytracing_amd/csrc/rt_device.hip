@@ -1464,7 +1464,12 @@ struct rt_ctx {
   int n_cus;
   float* d_slabs;       // partial-sum slabs of chunked renders, grown on demand
   size_t slab_floats;
+  void* d_stage[6];     // device staging of the host-buffer entry points (rt_render, rt_trace_closest, rt_tonemap), grown on demand
+  size_t stage_bytes[6];
   hipEvent_t ev0, ev1;
+  hipEvent_t ev_launch;      // recorded after the last enqueued render: a launch on another stream waits for it,
+  hipStream_t last_stream;   // because all launches of a context share its work counter and slabs
+  bool launched;
 };
 
 namespace {
@@ -1497,8 +1502,15 @@ int validate_scene(const rt_scene* s) {
   if (s->n_materials <= 0 || !s->materials) return rt::set_error(RT_ERR_INVALID, "scene has no materials");
   if (s->n_textures < 0 || s->n_objects < 0 || s->n_perlins < 0) return rt::set_error(RT_ERR_INVALID, "negative count");
   if (s->n_materials >= (1 << 19) || s->n_prims >= (1 << 23)) return rt::set_error(RT_ERR_UNSUPPORTED, "too many materials or primitives");
+  if ((s->n_textures > 0 && !s->textures) || (s->n_objects > 0 && !s->objects) || (s->n_perlins > 0 && !s->perlins) || (s->n_lights > 0 && !s->lights))
+    return rt::set_error(RT_ERR_INVALID, "a count is positive but its array pointer is null");
   if (s->n_lights < 0 || s->n_lights > 1) return rt::set_error(RT_ERR_UNSUPPORTED, "n_lights must be 0 or 1");
-  if (s->n_lights == 1 && s->lights[0].type != RT_LIGHT_XZ_RECT) return rt::set_error(RT_ERR_UNSUPPORTED, "light type must be RT_LIGHT_XZ_RECT");
+  if (s->n_lights == 1) {
+    const rt_light& l = s->lights[0];
+    if (l.type != RT_LIGHT_XZ_RECT) return rt::set_error(RT_ERR_UNSUPPORTED, "light type must be RT_LIGHT_XZ_RECT");
+    // XZRect::pdf_value divides by the rect's area (hitable.rs:249-251)
+    if (!(l.f[0] < l.f[1]) || !(l.f[2] < l.f[3])) return rt::set_error(RT_ERR_INVALID, "light rect must have x0 < x1 and z0 < z1");
+  }
   for (int i = 0; i < s->n_textures; ++i) {
     const rt_texture& t = s->textures[i];
     if (t.type == RT_TEX_CHECKER) {
@@ -1849,6 +1861,20 @@ DevCamera to_dev_camera(const rt_camera* c) {
   return d;
 }
 
+// Grows staging buffer `slot` of the context to at least `bytes` (never shrinks): the host-buffer entry points
+// reuse their device buffers from call to call instead of allocating and freeing each time.
+int stage(rt_ctx* ctx, int slot, size_t bytes, void** out) {
+  if (bytes > ctx->stage_bytes[slot]) {
+    if (ctx->d_stage[slot]) HIP_TRY(hipFree(ctx->d_stage[slot]));
+    ctx->d_stage[slot] = nullptr;
+    ctx->stage_bytes[slot] = 0;
+    HIP_TRY(hipMalloc(&ctx->d_stage[slot], bytes));
+    ctx->stage_bytes[slot] = bytes;
+  }
+  *out = ctx->d_stage[slot];
+  return RT_OK;
+}
+
 int launch_render(rt_ctx* ctx, const rt_camera* cam, const rt_render_params* p, float* d_sum, float* d_sumsq, bool stats, hipStream_t stream) {
   RenderArgs A;
   A.nx = p->nx; A.ny = p->ny; A.spp = p->spp; A.sample_begin = p->sample_begin; A.max_depth = p->max_depth; A.sky = p->sky;
@@ -1897,6 +1923,7 @@ int launch_render(rt_ctx* ctx, const rt_camera* cam, const rt_render_params* p, 
   }
   float* k_sum = d_sum;
   float* k_sumsq = d_sumsq;
+  unsigned* d_queue = ctx->d_queue;
   if (A.n_chunks > 1) {
     const size_t need = (size_t)A.n_chunks * per_image;
     if (need > ctx->slab_floats) {
@@ -1926,13 +1953,16 @@ int launch_render(rt_ctx* ctx, const rt_camera* cam, const rt_render_params* p, 
   // start when the first waves are done, find no item left and leave.  Never more waves than items.
   long long waves = 32LL * (ctx->n_cus > 0 ? ctx->n_cus : 1);
   if (waves > n_items) waves = n_items;
-  HIP_TRY(hipMemsetAsync(ctx->d_queue, 0, sizeof(unsigned), stream));
+  // All launches of a context share its counter and slabs:
+  // a launch on another stream than the last one first waits for that one to finish.
+  if (ctx->launched && ctx->last_stream != stream) HIP_TRY(hipStreamWaitEvent(stream, ctx->ev_launch, 0));
+  HIP_TRY(hipMemsetAsync(d_queue, 0, sizeof(unsigned), stream));
   if (p->shard_count > 1) {
     // a shard writes its own tiles only: everything else in the image (or in every partial image) is zero
     HIP_TRY(hipMemsetAsync(k_sum, 0, (size_t)A.n_chunks * n * sizeof(float), stream));
     if (k_sumsq) HIP_TRY(hipMemsetAsync(k_sumsq, 0, (size_t)A.n_chunks * n * sizeof(float), stream));
   }
-  hipLaunchKernelGGL(fn, dim3((unsigned)waves), block, lds_bytes, stream, ctx->dev, dc, A, k_sum, k_sumsq, ctx->d_stats, ctx->d_queue);
+  hipLaunchKernelGGL(fn, dim3((unsigned)waves), block, lds_bytes, stream, ctx->dev, dc, A, k_sum, k_sumsq, ctx->d_stats, d_queue);
   HIP_TRY(hipGetLastError());
   if (A.n_chunks > 1) {
     const size_t n4 = n / 4;
@@ -1942,6 +1972,9 @@ int launch_render(rt_ctx* ctx, const rt_camera* cam, const rt_render_params* p, 
     if (d_sumsq) hipLaunchKernelGGL(reduce_slabs_kernel, dim3(blocks), dim3(256), 0, stream, (const float4*)k_sumsq, n4, A.n_chunks, (float4*)d_sumsq);
   }
   HIP_TRY(hipGetLastError());
+  HIP_TRY(hipEventRecord(ctx->ev_launch, stream));
+  ctx->last_stream = stream;
+  ctx->launched = true;
   return RT_OK;
 }
 
@@ -1968,7 +2001,10 @@ int rt_create(int device_id, rt_ctx** out) {
   if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_queue, sizeof(unsigned));
   if (e == hipSuccess) e = hipEventCreate(&ctx->ev0);
   if (e == hipSuccess) e = hipEventCreate(&ctx->ev1);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ev_launch, hipEventDisableTiming);
   if (e != hipSuccess) {
+    if (ctx->d_stats) (void)hipFree(ctx->d_stats);
+    if (ctx->d_queue) (void)hipFree(ctx->d_queue);
     delete ctx;
     return hip_fail(e, "rt_create");
   }
@@ -1983,8 +2019,11 @@ int rt_destroy(rt_ctx* ctx) {
   if (ctx->d_stats) (void)hipFree(ctx->d_stats);
   if (ctx->d_queue) (void)hipFree(ctx->d_queue);
   if (ctx->d_slabs) (void)hipFree(ctx->d_slabs);
+  for (int k = 0; k < 6; ++k)
+    if (ctx->d_stage[k]) (void)hipFree(ctx->d_stage[k]);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+  if (ctx->ev_launch) (void)hipEventDestroy(ctx->ev_launch);
   delete ctx;
   return RT_OK;
 }
@@ -2156,11 +2195,8 @@ int rt_render(rt_ctx* ctx, const rt_camera* cam, const rt_render_params* params,
   HIP_TRY(hipSetDevice(ctx->device));
   const size_t bytes = (size_t)params->nx * params->ny * 3 * sizeof(float);
   float *d_sum = nullptr, *d_sumsq = nullptr;
-  HIP_TRY(hipMalloc((void**)&d_sum, bytes));
-  if (out_sumsq) {
-    hipError_t e = hipMalloc((void**)&d_sumsq, bytes);
-    if (e != hipSuccess) { (void)hipFree(d_sum); return hip_fail(e, "hipMalloc"); }
-  }
+  if ((rc = stage(ctx, 0, bytes, (void**)&d_sum)) != RT_OK) return rc;
+  if (out_sumsq && (rc = stage(ctx, 1, bytes, (void**)&d_sumsq)) != RT_OK) return rc;
   hipError_t e = hipSuccess;
   if (stats) e = hipMemset(ctx->d_stats, 0, 9 * sizeof(unsigned long long));
   if (e == hipSuccess) e = hipEventRecord(ctx->ev0, 0);
@@ -2182,8 +2218,6 @@ int rt_render(rt_ctx* ctx, const rt_camera* cam, const rt_render_params* params,
       stats->kernel_ms = ms;
     }
   }
-  (void)hipFree(d_sum);
-  if (d_sumsq) (void)hipFree(d_sumsq);
   if (rc != RT_OK) return rc;
   if (e != hipSuccess) return hip_fail(e, "rt_render");
   return RT_OK;
@@ -2204,13 +2238,14 @@ int rt_trace_closest(rt_ctx* ctx, const float* o, const float* d, size_t n, floa
   HIP_TRY(hipSetDevice(ctx->device));
   float *d_o = nullptr, *d_d = nullptr, *d_t = nullptr, *d_n = nullptr, *d_p = nullptr;
   int* d_id = nullptr;
-  hipError_t e = hipMalloc((void**)&d_o, n * 3 * sizeof(float));
-  if (e == hipSuccess) e = hipMalloc((void**)&d_d, n * 3 * sizeof(float));
-  if (e == hipSuccess) e = hipMalloc((void**)&d_t, n * sizeof(float));
-  if (e == hipSuccess) e = hipMalloc((void**)&d_id, n * sizeof(int));
-  if (e == hipSuccess && normal) e = hipMalloc((void**)&d_n, n * 3 * sizeof(float));
-  if (e == hipSuccess && p) e = hipMalloc((void**)&d_p, n * 3 * sizeof(float));
-  if (e == hipSuccess) e = hipMemcpy(d_o, o, n * 3 * sizeof(float), hipMemcpyHostToDevice);
+  int rc;
+  if ((rc = stage(ctx, 0, n * 3 * sizeof(float), (void**)&d_o)) != RT_OK) return rc;
+  if ((rc = stage(ctx, 1, n * 3 * sizeof(float), (void**)&d_d)) != RT_OK) return rc;
+  if ((rc = stage(ctx, 2, n * sizeof(float), (void**)&d_t)) != RT_OK) return rc;
+  if ((rc = stage(ctx, 3, n * sizeof(int), (void**)&d_id)) != RT_OK) return rc;
+  if (normal && (rc = stage(ctx, 4, n * 3 * sizeof(float), (void**)&d_n)) != RT_OK) return rc;
+  if (p && (rc = stage(ctx, 5, n * 3 * sizeof(float), (void**)&d_p)) != RT_OK) return rc;
+  hipError_t e = hipMemcpy(d_o, o, n * 3 * sizeof(float), hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemcpy(d_d, d, n * 3 * sizeof(float), hipMemcpyHostToDevice);
   if (e == hipSuccess) {
     size_t blocks = (n + 255) / 256;
@@ -2225,9 +2260,6 @@ int rt_trace_closest(rt_ctx* ctx, const float* o, const float* d, size_t n, floa
   if (e == hipSuccess) e = hipMemcpy(t, d_t, n * sizeof(float), hipMemcpyDeviceToHost);
   if (e == hipSuccess && normal) e = hipMemcpy(normal, d_n, n * 3 * sizeof(float), hipMemcpyDeviceToHost);
   if (e == hipSuccess && p) e = hipMemcpy(p, d_p, n * 3 * sizeof(float), hipMemcpyDeviceToHost);
-  void* ptrs[] = {d_o, d_d, d_t, d_id, d_n, d_p};
-  for (size_t i = 0; i < 6; ++i)
-    if (ptrs[i]) (void)hipFree(ptrs[i]);
   if (e != hipSuccess) return hip_fail(e, "rt_trace_closest");
   return RT_OK;
 }
@@ -2259,23 +2291,27 @@ int rt_selftest_reciprocal(rt_ctx* ctx, uint64_t* mismatches, uint32_t* examples
   return RT_OK;
 }
 
+int rt_tonemap_device(rt_ctx* ctx, const float* d_sum_rgb, int32_t nx, int32_t ny, int32_t spp_total, uint8_t* d_rgb8, void* hip_stream) {
+  if (!ctx || !d_sum_rgb || !d_rgb8 || nx <= 0 || ny <= 0 || spp_total <= 0) return rt::set_error(RT_ERR_INVALID, "rt_tonemap_device: bad argument");
+  HIP_TRY(hipSetDevice(ctx->device));
+  const size_t n = (size_t)nx * ny * 3;
+  hipLaunchKernelGGL(tonemap_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)hip_stream, d_sum_rgb, n, (float)spp_total, d_rgb8);
+  HIP_TRY(hipGetLastError());
+  return RT_OK;
+}
+
 int rt_tonemap(rt_ctx* ctx, const float* sum_rgb, int32_t nx, int32_t ny, int32_t spp_total, uint8_t* rgb8) {
   if (!ctx || !sum_rgb || !rgb8 || nx <= 0 || ny <= 0 || spp_total <= 0) return rt::set_error(RT_ERR_INVALID, "rt_tonemap: bad argument");
   HIP_TRY(hipSetDevice(ctx->device));
   const size_t n = (size_t)nx * ny * 3;
   float* d_in = nullptr;
   unsigned char* d_out = nullptr;
-  hipError_t e = hipMalloc((void**)&d_in, n * sizeof(float));
-  if (e == hipSuccess) e = hipMalloc((void**)&d_out, n);
-  if (e == hipSuccess) e = hipMemcpy(d_in, sum_rgb, n * sizeof(float), hipMemcpyHostToDevice);
-  if (e == hipSuccess) {
-    hipLaunchKernelGGL(tonemap_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, d_in, n, (float)spp_total, d_out);
-    e = hipGetLastError();
-  }
-  if (e == hipSuccess) e = hipMemcpy(rgb8, d_out, n, hipMemcpyDeviceToHost);
-  if (d_in) (void)hipFree(d_in);
-  if (d_out) (void)hipFree(d_out);
-  if (e != hipSuccess) return hip_fail(e, "rt_tonemap");
+  int rc;
+  if ((rc = stage(ctx, 0, n * sizeof(float), (void**)&d_in)) != RT_OK) return rc;
+  if ((rc = stage(ctx, 1, n, (void**)&d_out)) != RT_OK) return rc;
+  HIP_TRY(hipMemcpy(d_in, sum_rgb, n * sizeof(float), hipMemcpyHostToDevice));
+  if ((rc = rt_tonemap_device(ctx, d_in, nx, ny, spp_total, d_out, nullptr)) != RT_OK) return rc;
+  HIP_TRY(hipMemcpy(rgb8, d_out, n, hipMemcpyDeviceToHost));
   return RT_OK;
 }
 

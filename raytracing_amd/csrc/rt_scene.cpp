@@ -595,6 +595,7 @@ int rtb_light_xz_rect(rt_builder* b, double x0, double x1, double z0, double z1,
   std::memset(&l, 0, sizeof(l));
   l.type = RT_LIGHT_XZ_RECT;
   l.f[0] = (float)x0; l.f[1] = (float)x1; l.f[2] = (float)z0; l.f[3] = (float)z1; l.f[4] = (float)k;
+  b->tables.lights.clear();  // color() samples one shape (main.rs:177-178): registering again replaces it
   b->tables.lights.push_back(l);
   return (int)b->tables.lights.size() - 1;
 }

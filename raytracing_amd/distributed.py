@@ -27,6 +27,8 @@ def shard_params(params, rank, world, mode="samples"):
     if mode == "samples":
         # ranks take consecutive sample ranges; like `ns / threads` at main.rs:78 but
         # without dropping the remainder
+        if params.spp < world:  # checked on the totals, so every rank raises (none goes on into a reduce alone)
+            raise ValueError("fewer samples per pixel (%d) than ranks (%d)" % (params.spp, world))
         begin = params.spp * rank // world
         end = params.spp * (rank + 1) // world
         if end <= begin:

@@ -56,6 +56,11 @@ class Renderer(object):
                                           C.c_void_p(d_sumsq_ptr) if d_sumsq_ptr else None,
                                           C.c_void_p(stream) if stream else None))
 
+    def tonemap_device(self, d_sum_ptr, nx, ny, spp_total, d_rgb8_ptr, stream=None):
+        """main.rs:136-155 on device-resident buffers, enqueued on `stream`."""
+        check(_lib.lib().rt_tonemap_device(self._ctx, C.c_void_p(d_sum_ptr), nx, ny, spp_total, C.c_void_p(d_rgb8_ptr),
+                                           C.c_void_p(stream) if stream else None))
+
     def trace_closest(self, o, d, t_min=0.001, t_max=float("inf"), want_normal=False, want_p=False):
         """world.hit(r, t_min, t_max) of main.rs:166 for a batch of rays."""
         o = np.ascontiguousarray(o, dtype=np.float32)

@@ -106,6 +106,7 @@ class Scene(object):
         flat = _lib.rt_scene()
         check(_lib.lib().rtb_flatten(self._b, world.handle, C.byref(flat)))
         self._flat = flat
+        flat._keep = self  # the struct points into this Scene's buffers: keep it alive as long as the struct
         return flat
 
 

@@ -51,6 +51,53 @@ def gpu():
     r.close()
 
 
+class HipMemory(object):
+    """Device buffers for tests of the device-pointer entry points, through the
+    HIP runtime librt_amd.so itself is linked against (no torch: a second HIP
+    runtime in the process does not see the device once the first has it)."""
+
+    def __init__(self):
+        import ctypes as C
+        from raytracing_amd import _lib
+        _lib.lib()  # the library first: the soname below then resolves to the runtime it loaded
+        self.C = C
+        self.hip = C.CDLL("libamdhip64.so.7")
+        self.hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+        self.hip.hipFree.argtypes = [C.c_void_p]
+        self.hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        self.hip.hipMemset.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
+        self.live = []
+
+    def alloc(self, nbytes, fill_byte=0xFF):
+        p = self.C.c_void_p()
+        assert self.hip.hipMalloc(self.C.byref(p), nbytes) == 0
+        assert self.hip.hipMemset(p, fill_byte, nbytes) == 0
+        self.live.append(p)
+        return p.value
+
+    def sync(self):
+        assert self.hip.hipDeviceSynchronize() == 0
+
+    def to_host(self, ptr, dtype, count):
+        out = np.empty(count, dtype=dtype)
+        self.sync()
+        assert self.hip.hipMemcpy(out.ctypes.data, ptr, out.nbytes, 2) == 0  # hipMemcpyDeviceToHost
+        return out
+
+    def free_all(self):
+        for p in self.live:
+            self.hip.hipFree(p)
+        self.live = []
+
+
+@pytest.fixture()
+def hipmem(gpu):
+    m = HipMemory()
+    yield m
+    m.sync()
+    m.free_all()
+
+
 def cornell_ray_batch(cornell, n, seed):
     """Seeded rays for nearest-hit parity in the Cornell box: camera rays,
     rays from random interior points in random directions (what cosine bounces

@@ -71,7 +71,9 @@ def test_shard_params_cover_every_sample_once():
         assert all(a[1] == b[0] for a, b in zip(ranges, ranges[1:]))
     q = shard_params(p, 2, 4, "tiles")
     assert (q.shard_index, q.shard_count, q.spp, q.sample_begin) == (2, 4, 1000, 5)
-    with pytest.raises(ValueError):
-        shard_params(make_params(8, 8, 3), 0, 8, "samples")
+    # fewer samples than ranks: every rank raises (a rank that went on alone would hang in the reduce)
+    for r in range(8):
+        with pytest.raises(ValueError):
+            shard_params(make_params(8, 8, 3), r, 8, "samples")
     with pytest.raises(ValueError):
         shard_params(p, 4, 4, "samples")

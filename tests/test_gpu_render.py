@@ -132,6 +132,49 @@ def test_render_matches_oracle_tonemapped(gpu, orc, cornell):
     assert np.abs(blocks(img) - blocks(oimg)).max() < 3.0
 
 
+def test_device_resident_tonemap_equals_the_host_entry_point(gpu, hipmem, cornell):
+    """main.rs:136-155 on the buffers rt_render_device wrote: render, tonemap and
+    one copy of the 8-bit image, with nothing allocated or staged by the library."""
+    from raytracing_amd import make_params
+    gpu.upload_scene(cornell.flat)
+    p = make_params(80, 56, 40, seed=77)
+    n = 80 * 56 * 3
+    d_sum, d_u8 = hipmem.alloc(n * 4), hipmem.alloc(n)
+    gpu.render_device(cornell.camera, p, d_sum, None, None)
+    gpu.tonemap_device(d_sum, 80, 56, 40, d_u8, None)
+    img = hipmem.to_host(d_u8, np.uint8, n).reshape(56, 80, 3)
+    sums = hipmem.to_host(d_sum, np.float32, n).reshape(56, 80, 3)
+    assert np.array_equal(sums, gpu.render(cornell.camera, p))
+    assert np.array_equal(img, gpu.tonemap(sums, 40))
+    assert img.max() == 255 and img.min() == 0
+
+
+def test_upload_refuses_null_arrays_and_empty_light_rects(gpu, cornell):
+    """A count above zero with a null array, or a light rect of no area (its pdf
+    divides by the area, hitable.rs:249-251), is an error return, not a crash."""
+    import ctypes as C
+    from raytracing_amd import _lib
+    from raytracing_amd._lib import RT_ERR_INVALID, RtError
+    for field in ("lights", "textures", "objects"):
+        bad = _lib.rt_scene()
+        for name, _ in _lib.rt_scene._fields_:
+            setattr(bad, name, getattr(cornell.flat, name))
+        setattr(bad, field, C.cast(None, type(getattr(bad, field))))
+        with pytest.raises(RtError) as e:
+            gpu.upload_scene(bad)
+        assert e.value.code == RT_ERR_INVALID
+    bad = _lib.rt_scene()
+    for name, _ in _lib.rt_scene._fields_:
+        setattr(bad, name, getattr(cornell.flat, name))
+    light = _lib.rt_light()
+    light.f[0], light.f[1], light.f[2], light.f[3], light.f[4] = 213.0, 213.0, 227.0, 332.0, 554.0
+    bad.lights = C.pointer(light)
+    with pytest.raises(RtError) as e:
+        gpu.upload_scene(bad)
+    assert e.value.code == RT_ERR_INVALID
+    gpu.upload_scene(cornell.flat)
+
+
 def test_render_argument_errors(gpu, cornell):
     from raytracing_amd import RtError
     gpu.upload_scene(cornell.flat)

@@ -11,7 +11,7 @@ import pytest
 from conftest import ROOT
 from raytracing_amd import RtError, Scene, _lib
 from raytracing_amd import scene as S
-from raytracing_amd.scenes import cornell_box_scene
+from raytracing_amd.scenes import MAIN_RS_LIGHT_SHAPE, cornell_box_scene
 
 
 def test_library_exports_every_declared_symbol():
@@ -197,6 +197,25 @@ def test_light_shape_read_from_the_scene_equals_the_hard_coded_one():
         world = S.HitableList.new([S.Sphere.new(S.vec3(0, 0, 0), 1.0, S.Lambertian.new_from_color(S.vec3(0.5, 0.5, 0.5)))])
         assert c.light_from_world(world) == 0
         assert c.flatten(world).n_lights == 0
+
+
+def test_registering_a_light_shape_again_replaces_it_and_flat_scenes_keep_their_owner():
+    """color() samples one shape (main.rs:177-178): a second registration on the
+    same Scene replaces the first (rendering twice from one Scene used to leave two
+    lights, which the upload refuses); the rt_scene a flatten returns keeps its
+    Scene alive, since its pointers lead into the Scene's buffers."""
+    import gc
+    with Scene(1) as sc:
+        cam, world = cornell_box_scene(1.0)
+        sc.light_xz_rect(0.0, 1.0, 0.0, 1.0, 5.0)
+        sc.light_xz_rect(*MAIN_RS_LIGHT_SHAPE)
+        flat = sc.flatten(world)
+    assert flat.n_lights == 1
+    assert [flat.lights[0].f[k] for k in range(5)] == list(MAIN_RS_LIGHT_SHAPE)
+    assert flat._keep is sc
+    del sc, cam, world
+    gc.collect()
+    assert flat.n_prims == 18 and flat.prims[17].type & 0xFF in (1, 2, 3)
 
 
 def test_cpp_host_program_fails_loudly_without_a_device(tmp_path):
