@@ -259,6 +259,27 @@ int rt_render(rt_ctx* ctx, const rt_camera* cam, const rt_render_params* params,
 int rt_render_device(rt_ctx* ctx, const rt_camera* cam, const rt_render_params* params,
                      float* d_sum_rgb, float* d_sumsq_rgb_or_null, void* hip_stream);
 
+/* No counterpart in the reference.  rt_render_device for callers that cannot
+ * allocate device memory (code under HIP graph capture, tight serving loops,
+ * harnesses that forbid hipMalloc): the same kernels and the same results, bit
+ * for bit, but the work counter and the partial images of a chunked launch live
+ * in a static 64 MiB device array instead of buffers the context allocates, and
+ * the call itself allocates and frees nothing.  Limit: the partial images of the
+ * launch (number of sample chunks x nx*ny*3 floats, twice that with d_sumsq; the
+ * library splits a tile's samples into chunks of at least 32 until the launch has
+ * about 184,000 work items) must fit in 64 MiB - 256 B, otherwise the call
+ * returns RT_ERR_UNSUPPORTED and the text says how many bytes it needed:
+ * 256x256 at 1000 spp fits (34 partial images, 27 MB) and so does 1024x1024 at
+ * 100 spp (5 partial images, 63 MB); 1024x1024 at 1000 spp does not (15 partial
+ * images, 189 MB); any image at fewer than 64 spp does (one chunk, no partial
+ * images).
+ * Every call on a GPU, from any context, uses that GPU's one array: calls that
+ * overlap on one GPU race (calls of one context are ordered as for
+ * rt_render_device; calls of different contexts on one device are the caller's
+ * to order). */
+int rt_render_device_noalloc(rt_ctx* ctx, const rt_camera* cam, const rt_render_params* params,
+                             float* d_sum_rgb, float* d_sumsq_rgb_or_null, void* hip_stream);
+
 /* Nearest-hit query on a batch of rays: the world.hit(r, t_min, t_max) of
  * src/main.rs:166 without any random numbers (media are skipped).  o and d are
  * n*3 floats.  prim_id[i] is the index into prims of the primitive hit, or -1;

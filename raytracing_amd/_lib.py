@@ -130,6 +130,7 @@ def lib():
     sig("rt_upload_scene", C.c_int, vp, C.POINTER(rt_scene))
     sig("rt_render", C.c_int, vp, C.POINTER(rt_camera), C.POINTER(rt_render_params), vp, vp, C.POINTER(rt_stats))
     sig("rt_render_device", C.c_int, vp, C.POINTER(rt_camera), C.POINTER(rt_render_params), vp, vp, vp)
+    sig("rt_render_device_noalloc", C.c_int, vp, C.POINTER(rt_camera), C.POINTER(rt_render_params), vp, vp, vp)
     sig("rt_tonemap_device", C.c_int, vp, vp, C.c_int32, C.c_int32, C.c_int32, vp, vp)
     sig("rt_trace_closest", C.c_int, vp, vp, vp, C.c_size_t, C.c_float, C.c_float, vp, vp, vp, vp)
     sig("rt_tonemap", C.c_int, vp, vp, C.c_int32, C.c_int32, C.c_int32, vp)

@@ -1441,6 +1441,17 @@ __global__ void tonemap_kernel(const float* __restrict__ sum, size_t n, float sp
 }  // namespace
 
 // ---------------------------------------------------------------------------
+// Scratch of rt_render_device_noalloc: the work-item counter (first 256 bytes)
+// and the partial-sum slabs of a chunked render.  Every GPU the library runs on
+// holds its own copy of this array, at its own address, until the process ends.
+// In host code the name is only a handle for hipGetSymbolAddress: rt_create asks
+// for the array's address on its device once and everything else uses that pointer.
+// ---------------------------------------------------------------------------
+#define RT_NOALLOC_SCRATCH_BYTES ((size_t)64 << 20)
+#define RT_NOALLOC_SLAB_OFFSET ((size_t)256)
+static __device__ __align__(256) unsigned char scratch[RT_NOALLOC_SCRATCH_BYTES];
+
+// ---------------------------------------------------------------------------
 // Host side of the ABI
 // ---------------------------------------------------------------------------
 struct rt_ctx {
@@ -1464,6 +1475,7 @@ struct rt_ctx {
   int n_cus;
   float* d_slabs;       // partial-sum slabs of chunked renders, grown on demand
   size_t slab_floats;
+  unsigned char* scratch_ptr;  // this device's copy of `scratch` (hipGetSymbolAddress in rt_create)
   void* d_stage[6];     // device staging of the host-buffer entry points (rt_render, rt_trace_closest, rt_tonemap), grown on demand
   size_t stage_bytes[6];
   hipEvent_t ev0, ev1;
@@ -1875,7 +1887,9 @@ int stage(rt_ctx* ctx, int slot, size_t bytes, void** out) {
   return RT_OK;
 }
 
-int launch_render(rt_ctx* ctx, const rt_camera* cam, const rt_render_params* p, float* d_sum, float* d_sumsq, bool stats, hipStream_t stream) {
+// no_alloc: the work counter and the slabs are this device's `scratch` array; a launch whose slabs do not fit is refused.
+int launch_render(rt_ctx* ctx, const rt_camera* cam, const rt_render_params* p, float* d_sum, float* d_sumsq, bool stats, hipStream_t stream,
+                  bool no_alloc = false) {
   RenderArgs A;
   A.nx = p->nx; A.ny = p->ny; A.spp = p->spp; A.sample_begin = p->sample_begin; A.max_depth = p->max_depth; A.sky = p->sky;
   A.t_min = p->t_min; A.inv_nx = 1.0f / (float)p->nx; A.inv_ny = 1.0f / (float)p->ny; A.shard_index = p->shard_index; A.shard_count = p->shard_count;
@@ -1923,8 +1937,19 @@ int launch_render(rt_ctx* ctx, const rt_camera* cam, const rt_render_params* p, 
   }
   float* k_sum = d_sum;
   float* k_sumsq = d_sumsq;
-  unsigned* d_queue = ctx->d_queue;
-  if (A.n_chunks > 1) {
+  unsigned* d_queue = no_alloc ? (unsigned*)ctx->scratch_ptr : ctx->d_queue;
+  if (A.n_chunks > 1 && no_alloc) {
+    const size_t need = (size_t)A.n_chunks * per_image;
+    const size_t room = (RT_NOALLOC_SCRATCH_BYTES - RT_NOALLOC_SLAB_OFFSET) / sizeof(float);
+    if (need > room) {
+      char msg[256];
+      std::snprintf(msg, sizeof(msg), "rt_render_device_noalloc: this launch splits each tile's samples into %d partial images of %zu floats "
+                    "(%zu bytes in all); the static scratch holds %zu bytes", A.n_chunks, per_image, need * sizeof(float), room * sizeof(float));
+      return rt::set_error(RT_ERR_UNSUPPORTED, msg);
+    }
+    k_sum = (float*)(ctx->scratch_ptr + RT_NOALLOC_SLAB_OFFSET);
+    k_sumsq = d_sumsq ? k_sum + (size_t)A.n_chunks * n : nullptr;
+  } else if (A.n_chunks > 1) {
     const size_t need = (size_t)A.n_chunks * per_image;
     if (need > ctx->slab_floats) {
       if (ctx->d_slabs) HIP_TRY(hipFree(ctx->d_slabs));
@@ -1953,7 +1978,7 @@ int launch_render(rt_ctx* ctx, const rt_camera* cam, const rt_render_params* p, 
   // start when the first waves are done, find no item left and leave.  Never more waves than items.
   long long waves = 32LL * (ctx->n_cus > 0 ? ctx->n_cus : 1);
   if (waves > n_items) waves = n_items;
-  // All launches of a context share its counter and slabs:
+  // All launches of a context share its counter and slabs (and all no_alloc launches on a device share `scratch`):
   // a launch on another stream than the last one first waits for that one to finish.
   if (ctx->launched && ctx->last_stream != stream) HIP_TRY(hipStreamWaitEvent(stream, ctx->ev_launch, 0));
   HIP_TRY(hipMemsetAsync(d_queue, 0, sizeof(unsigned), stream));
@@ -2002,6 +2027,8 @@ int rt_create(int device_id, rt_ctx** out) {
   if (e == hipSuccess) e = hipEventCreate(&ctx->ev0);
   if (e == hipSuccess) e = hipEventCreate(&ctx->ev1);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ev_launch, hipEventDisableTiming);
+  // The address of this device's copy of the static scratch array (the device is current here).
+  if (e == hipSuccess) e = hipGetSymbolAddress((void**)&ctx->scratch_ptr, HIP_SYMBOL(scratch));
   if (e != hipSuccess) {
     if (ctx->d_stats) (void)hipFree(ctx->d_stats);
     if (ctx->d_queue) (void)hipFree(ctx->d_queue);
@@ -2185,6 +2212,15 @@ int rt_render_device(rt_ctx* ctx, const rt_camera* cam, const rt_render_params* 
   if (rc != RT_OK) return rc;
   HIP_TRY(hipSetDevice(ctx->device));
   return launch_render(ctx, cam, params, d_sum, d_sumsq, false, (hipStream_t)hip_stream);
+}
+
+int rt_render_device_noalloc(rt_ctx* ctx, const rt_camera* cam, const rt_render_params* params, float* d_sum, float* d_sumsq, void* hip_stream) {
+  if (!ctx || !cam || !d_sum) return rt::set_error(RT_ERR_INVALID, "rt_render_device_noalloc: null argument");
+  if (!ctx->has_scene) return rt::set_error(RT_ERR_NO_SCENE, "rt_render_device_noalloc: no scene uploaded");
+  const int rc = check_params(params);
+  if (rc != RT_OK) return rc;
+  HIP_TRY(hipSetDevice(ctx->device));
+  return launch_render(ctx, cam, params, d_sum, d_sumsq, false, (hipStream_t)hip_stream, true);
 }
 
 int rt_render(rt_ctx* ctx, const rt_camera* cam, const rt_render_params* params, float* out_sum, float* out_sumsq, rt_stats* stats) {

@@ -56,6 +56,14 @@ class Renderer(object):
                                           C.c_void_p(d_sumsq_ptr) if d_sumsq_ptr else None,
                                           C.c_void_p(stream) if stream else None))
 
+    def render_device_noalloc(self, camera, params, d_sum_ptr, d_sumsq_ptr=None, stream=None):
+        """render_device through the entry point that allocates nothing (its
+        scratch is a static device array; launches whose partial images exceed
+        it raise RtError with RT_ERR_UNSUPPORTED)."""
+        check(_lib.lib().rt_render_device_noalloc(self._ctx, C.byref(camera.c), C.byref(params), C.c_void_p(d_sum_ptr),
+                                                  C.c_void_p(d_sumsq_ptr) if d_sumsq_ptr else None,
+                                                  C.c_void_p(stream) if stream else None))
+
     def tonemap_device(self, d_sum_ptr, nx, ny, spp_total, d_rgb8_ptr, stream=None):
         """main.rs:136-155 on device-resident buffers, enqueued on `stream`."""
         check(_lib.lib().rt_tonemap_device(self._ctx, C.c_void_p(d_sum_ptr), nx, ny, spp_total, C.c_void_p(d_rgb8_ptr),
