@@ -232,20 +232,38 @@ template <class P> struct World {
     const Vec oc = r.origin() - center;
     const R a = dot<P>(r.direction(), r.direction());
     const R b = dot<P>(oc, r.direction());
-    R c, discriminant;
-    if (P::fused) {
-      c = std::fma(-radius, radius, dot<P>(oc, oc));
-      discriminant = std::fma(b, b, -(a * c));
+    R discriminant, near_t, far_t;
+    if (sizeof(R) == 4) {
+      // fp32 only, not in the reference: b*b - a*c cancels badly when the origin is far from a small sphere (at 2000
+      // units from a sphere of radius 2.4 its absolute error is a tenth of the discriminant's whole range, so grazing
+      // hits come and go and t is off by up to 3e-4 relative).  The same quantity from the component of oc that is
+      // perpendicular to the ray, l = oc - (b/a) d:  b*b - a*c = a * (r*r - l.l), whose terms are of the sphere's own
+      // size.  Roots: t = -b/a -+ sqrt((r*r - l.l) / a).  The sign test is the reference's (a > 0).
+      const R inv_a = R(1) / a;
+      const R k = b * inv_a;
+      const Vec dir = r.direction();
+      R h;
+      if (P::fused) {
+        const Vec l(std::fma(-k, dir.x, oc.x), std::fma(-k, dir.y, oc.y), std::fma(-k, dir.z, oc.z));
+        h = std::fma(radius, radius, -dot<P>(l, l));
+      } else {
+        const Vec l = oc - dir * scalar<R>(k);
+        h = radius * radius - dot<P>(l, l);
+      }
+      discriminant = h;
+      const R sq = std::sqrt(h * inv_a);
+      near_t = -k - sq;
+      far_t = -k + sq;
     } else {
-      c = dot<P>(oc, oc) - radius * radius;
+      const R c = dot<P>(oc, oc) - radius * radius;
       discriminant = b * b - a * c;
+      const R sq = std::sqrt(discriminant);
+      near_t = (-b - sq) / a;
+      far_t = (-b + sq) / a;
     }
     if (discriminant > R(0)) {
-      const R sq = std::sqrt(discriminant);
-      const R inv_a = R(1) / a;
       for (int root = 0; root < 2; ++root) {
-        const R num = root == 0 ? (-b - sq) : (-b + sq);
-        const R temp = P::fused ? num * inv_a : num / a;
+        const R temp = root == 0 ? near_t : far_t;
         if (temp < t_max && temp > t_min) {
           rec.t = temp;
           rec.p = r.point_at_parameter(rec.t);

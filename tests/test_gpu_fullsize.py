@@ -1,0 +1,170 @@
+"""The named configurations at their own sizes: the 2^20-sphere tree (2^21 nodes,
+depth past 20, the packed child references of the stack traversal, a 64 MB node
+array), the final scene at 1920x1080 and the Cornell box with glass and smoke at
+7680x4320, each against the CPU oracle on the same random stream at one or two
+samples per pixel, plus properties that do not depend on the size (event counts,
+sample ranges adding up, tile shards partitioning the frame)."""
+import numpy as np
+import pytest
+
+from raytracing_amd import Scene, make_params
+from raytracing_amd import scenes
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def stress_scene():
+    """sphere_stress_scene at 2^20 spheres with the reference's median-split tree."""
+    with Scene(0x5EED0000) as sc:
+        cam, world = scenes.sphere_stress_scene(16.0 / 9.0, 1 << 20)
+        sc.light_xz_rect(*scenes.STRESS_LIGHT_SHAPE)
+        flat = sc.flatten(world)
+    assert flat.n_nodes == (1 << 21) + 1 and flat.n_prims == (1 << 20) + 1
+    return cam, flat
+
+
+def _stress_rays(cam, n, seed):
+    """Camera rays of the 3840x2160 frame, rays between random points of the cloud
+    (what bounces look like), axis-parallel rays and rays aimed at sphere centres."""
+    rng = np.random.RandomState(seed)
+    c = cam.c
+    org = np.array(list(c.origin))
+    llc, hor, ver = np.array(list(c.lower_left_corner)), np.array(list(c.horizontal)), np.array(list(c.vertical))
+    k = n // 4
+    uv = rng.rand(k, 2)
+    o0 = np.repeat(org[None, :], k, 0)
+    d0 = llc[None, :] + uv[:, :1] * hor[None, :] + uv[:, 1:] * ver[None, :] - org[None, :]
+    o1 = rng.uniform(0.0, 1000.0, (k, 3))
+    d1 = rng.uniform(0.0, 1000.0, (k, 3)) - o1
+    o2 = rng.uniform(-100.0, 1100.0, (k, 3))
+    d2 = np.zeros((k, 3))
+    d2[np.arange(k), rng.randint(0, 3, k)] = rng.choice([-1.0, 1.0], k)
+    o3 = rng.uniform(-200.0, 1200.0, (n - 3 * k, 3))
+    d3 = rng.normal(size=(n - 3 * k, 3))
+    o = np.concatenate([o0, o1, o2, o3]).astype(np.float32)
+    d = np.concatenate([d0, d1, d2, d3]).astype(np.float32)
+    return o, d
+
+
+def _check_trace(gpu, orc, flat, o, d):
+    prim, t, nrm, p = gpu.trace_closest(o, d, want_normal=True, want_p=True)
+    op, ot, on, opp = orc.trace_closest(flat, o, d, mode=orc.ORC_F32_FUSED, want_normal=True, want_p=True)
+    assert np.array_equal(prim, op), "primitive ids differ on %d rays" % (prim != op).sum()
+    assert np.array_equal(t, ot.astype(np.float32))
+    assert np.array_equal(nrm, on.astype(np.float32)) and np.array_equal(p, opp.astype(np.float32))
+    # against the reference's own arithmetic (f64): the same sphere on rays in general position, t within 1e-5
+    dp, dt = orc.trace_closest(flat, o, d, mode=orc.ORC_F64)
+    same = prim == dp
+    assert same.mean() > 0.999, same.mean()
+    hit = same & (prim >= 0)
+    rel = np.abs(t[hit].astype(np.float64) - dt[hit]) / np.maximum(dt[hit], 1e-3)
+    assert (rel < 1e-5).mean() > 0.999, (rel < 1e-5).mean()  # the rest graze a sphere (nearly zero discriminant)
+    assert (prim >= 0).mean() > 0.5
+    return prim
+
+
+def test_million_sphere_tree_nearest_hits(gpu, orc, stress_scene):
+    """24,000 rays through the 2^21-node reference tree: bit-exact against the fp32
+    oracle (id, t, point, normal), same sphere as the f64 oracle."""
+    cam, flat = stress_scene
+    gpu.upload_scene(flat)
+    o, d = _stress_rays(cam, 24000, 11)
+    prim = _check_trace(gpu, orc, flat, o, d)
+    assert len(np.unique(prim)) > 5000  # spread over the tree, not a corner of it
+
+
+def test_million_sphere_device_built_tree_nearest_hits(gpu, orc, stress_scene):
+    """The same rays through the tree rt_build_lbvh makes on the device from the
+    same 2^20+1 leaves: the oracle walks that node array too, so parity is again
+    bit for bit; against the reference tree only exactly tied hits may differ."""
+    cam, flat = stress_scene
+    lb = gpu.build_lbvh(flat)
+    gpu.upload_scene(lb)
+    o, d = _stress_rays(cam, 24000, 12)
+    prim = _check_trace(gpu, orc, lb, o, d)
+    gpu.upload_scene(flat)
+    prim_ref, t_ref = gpu.trace_closest(o, d)
+    assert (prim == prim_ref).mean() > 0.9999
+
+
+def test_million_sphere_render_at_3840x2160(gpu, orc, stress_scene):
+    """The named frame at one sample per pixel.  The oracle takes a minute for the
+    whole frame, so it renders every 40th 64x64 block (tile shard 7 of 40) and the
+    device frame is compared on those blocks; the whole frame is checked through
+    its event counts and through the same tile shard rendered by the device."""
+    cam, flat = stress_scene
+    gpu.upload_scene(flat)
+    nx, ny = 3840, 2160
+    p = make_params(nx, ny, 1, seed=9)
+    s, st = gpu.render(cam, p, want_stats=True)
+    assert st.paths == nx * ny and st.rays >= st.paths and st.sphere_tests > st.rays
+    assert np.isfinite(s).all() and s.sum() > 0
+    q = make_params(nx, ny, 1, seed=9, shard_index=7, shard_count=40)
+    part = gpu.render(cam, q)
+    mask = part.sum(axis=2) != 0
+    assert np.array_equal(part[mask], s[mask])
+    o = orc.render(flat, cam.c, q, mode=orc.ORC_F32_FUSED, n_threads=16, want_sumsq=False).astype(np.float32)
+    blocks = np.zeros((ny, nx), dtype=bool)
+    for b in range(7, 60 * 34, 40):
+        by, bx = divmod(b, 60)
+        blocks[by * 64:(by + 1) * 64, bx * 64:(bx + 1) * 64] = True
+    assert not part[~blocks].any() and not o[~blocks].any()
+    a, b = part[blocks], o[blocks]
+    assert np.isclose(a, b, rtol=5e-3, atol=5e-3).mean() > 0.9, np.isclose(a, b, rtol=5e-3, atol=5e-3).mean()
+    assert abs(a.sum() - b.sum()) / b.sum() < 0.03, (a.sum(), b.sum())
+
+
+def test_final_scene_at_1920x1080(gpu, orc):
+    """The final scene's own frame at one sample per pixel, whole frame against the
+    oracle on the same stream; two sample ranges add up to the two-sample frame."""
+    with Scene(0x5EED0000) as sc:
+        cam, world = scenes.final_scene(1920.0 / 1080.0)
+        sc.light_xz_rect(*scenes.FINAL_LIGHT_SHAPE)
+        flat = sc.flatten(world)
+    gpu.upload_scene(flat)
+    nx, ny = 1920, 1080
+    p = make_params(nx, ny, 1, seed=21)
+    s, st = gpu.render(cam, p, want_stats=True)
+    assert st.paths == nx * ny
+    o, ost = orc.render(flat, cam.c, p, mode=orc.ORC_F32_FUSED, n_threads=16, want_sumsq=False, want_stats=True)
+    close = np.isclose(s, o, rtol=5e-3, atol=5e-3)
+    assert close.mean() > 0.9, close.mean()
+    assert abs(s.sum() - o.sum()) / o.sum() < 0.02, (s.sum(), o.sum())
+    # the device ends a path whose weight has become exactly zero (its sample is zero whatever follows); the oracle walks on
+    assert 0.8 * ost.rays < st.rays <= ost.rays, (st.rays, ost.rays)
+    for ys, xs in ((slice(0, 64), slice(0, 64)), (slice(ny - 64, ny), slice(nx - 64, nx)), (slice(500, 600), slice(900, 1000))):
+        assert close[ys, xs].mean() > 0.85
+    second = gpu.render(cam, make_params(nx, ny, 1, seed=21, sample_begin=1))
+    both = gpu.render(cam, make_params(nx, ny, 2, seed=21))
+    assert np.allclose(both, s + second, rtol=1e-6, atol=1e-6)
+
+
+def test_cornell_glass_and_smoke_at_7680x4320(gpu, orc):
+    """The 8K frame (33 M pixels, 518,400 tiles, 12 B x 33 M = 398 MB of sums) at
+    one sample per pixel against the oracle on the same stream; the tile shards of
+    a 5-way split partition it exactly."""
+    nx, ny = 7680, 4320
+    with Scene(0x5EED0000) as sc:
+        cam, world = scenes.cornell_smoke_scene(float(nx) / ny, smoke=True)
+        sc.light_xz_rect(*scenes.SMOKE_LIGHT_SHAPE)
+        flat = sc.flatten(world)
+    gpu.upload_scene(flat)
+    p = make_params(nx, ny, 1, seed=33)
+    s, st = gpu.render(cam, p, want_stats=True)
+    assert st.paths == nx * ny
+    o = orc.render(flat, cam.c, p, mode=orc.ORC_F32_FUSED, n_threads=16, want_sumsq=False)
+    close = np.isclose(s, o, rtol=5e-3, atol=5e-3)
+    assert close.mean() > 0.95, close.mean()
+    assert abs(float(s.sum(dtype=np.float64)) - o.sum()) / o.sum() < 0.01
+    for ys, xs in ((slice(0, 64), slice(0, 64)), (slice(ny - 64, ny), slice(nx - 64, nx)), (slice(2100, 2200), slice(3800, 3900))):
+        assert close[ys, xs].mean() > 0.9
+    del o, close
+    total = np.zeros_like(s)
+    owner = np.zeros((ny, nx), dtype=np.int32)
+    for k in range(5):
+        part = gpu.render(cam, make_params(nx, ny, 1, seed=33, shard_index=k, shard_count=5))
+        total += part
+        owner += (part.sum(axis=2) != 0)
+    assert owner.max() <= 1
+    assert np.array_equal(total, s)
