@@ -55,6 +55,8 @@ def main():
     ap.add_argument("--cpu-spp", type=int, default=256, help="samples per pixel of the CPU baseline's bounded run")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stats", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the short runs of the other named configurations (single GPU only; they add about a minute)")
     ap.add_argument("--no-overlap", action="store_true", help="several ranks: wait for each image's reduce before rendering the next")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="N ranks share GPU 0 and exchange over gloo: checks the multi-rank control flow on a one-GPU box, not a benchmark")
@@ -165,7 +167,7 @@ def main():
     # HBM bytes per launch of the dominant kernel from a committed PMC profile of this exact workload
     # (rocprofv3 FETCH_SIZE / WRITE_SIZE passes; tools/profile.sh), null for any other workload
     traffic = None
-    traffic_file = os.path.join(ROOT, "profiles", "r1", "traffic.json")
+    traffic_file = os.path.join(ROOT, "profiles", "r2", "traffic.json")
     if (nx, ny, spp, world) == (1024, 1024, 1000, 1) and os.path.exists(traffic_file):
         for name, t in json.load(open(traffic_file)).items():
             if name.startswith("render_kernel"):
@@ -180,8 +182,7 @@ def main():
         ex_flops = algorithmic_flops(stats)
         executed = {"flops_per_path": round(ex_flops / float(stats.paths), 1), "rays_per_path": round(stats.rays / float(stats.paths), 3),
                     "TFLOP/s": round(ex_flops / (kernel_ms * 1e-3) / 1e12, 3),
-                    "note": "what the kernel itself evaluates (its event counters x the same per-event constants): it box-tests only "
-                            "the winning leaf, tests every primitive of the 8 leaves and ends zero-weight paths early"}
+                    }
 
     # CPU baseline (rank 0, single GPU only): the f64 restatement run the reference's way on a bounded sample; its event
     # counters give the reference algorithm's work per path
@@ -213,26 +214,60 @@ def main():
             cpu["all_cores"] = {"value": round(nx * ny * args.cpu_spp / cdt / 1e6, 3), "unit": "Mpaths/s", "cores": share,
                                 "sample": "the same sample on %d threads (%.1f s)" % (share, cdt)}
 
+    # Roofline of the dominant kernel: the algorithmic fp32 operations of what THIS launch evaluated (its event
+    # counters x the per-event constants above) over the kernel's duration by HIP events on its launch stream.
     roofline = None
-    if ref_flops_per_path is not None:
-        paths_per_launch = float(nx) * ny * params.spp
-        flops = ref_flops_per_path * paths_per_launch
-        achieved = flops / (kernel_ms * 1e-3) / 1e12
+    paths_per_launch = float(nx) * ny * params.spp
+    if executed is not None:
+        achieved = executed["TFLOP/s"]
         roofline = {
             "bound": "valu", "kernel": "render_kernel", "achieved": round(achieved, 3), "peak": VALU_PEAK_TFLOPS,
             "unit": "TFLOP/s", "frac": round(achieved / VALU_PEAK_TFLOPS, 4), "traffic": traffic,
-            "kernel_ms": round(kernel_ms, 3), "flops_per_path": round(ref_flops_per_path, 1), "paths_per_launch": int(paths_per_launch),
-            "flops_per_path_source": ref_source,
-            "definition": "algorithmic fp32 operations of the reference algorithm per path (unpruned BvhNode::hit with every "
-                          "Aabb::hit it makes, 2.81 rays per path) x paths per launch / kernel time; 'executed' counts the "
-                          "kernel's own, smaller, work instead",
-            "executed": executed,
+            "kernel_ms": round(kernel_ms, 3), "flops_per_path": executed["flops_per_path"], "paths_per_launch": int(paths_per_launch),
+            "definition": "algorithmic fp32 operations of the events this launch evaluated (rt_stats of the counting build of the "
+                          "same kernel: box tests, rect tests, instance moves, hits, scattering vertices, rays, paths, each x its "
+                          "per-event constant) / kernel time (HIP events on the launch stream)",
+            "rays_per_path": executed["rays_per_path"],
             "algorithmic_hbm_bytes_per_launch": nx * ny * 12,
-            "traffic_note": "HBM bytes per launch (PMC, profiles/r1): the kernel writes one 12.6 MB partial image per sample "
-                            "chunk, added up by reduce_slabs_kernel; reads are 0.2 MB",
+            "traffic_note": "HBM bytes per launch from the PMC profile of this workload (profiles/r2/traffic.json); the only "
+                            "algorithmic HBM stream is the nx*ny*12-byte image",
             "note": "no MFMA and no HBM stream on this path: the scene is 2 KB and lives in SGPRs/LDS; "
                     "the bound is the fp32 vector ALU",
         }
+        if ref_flops_per_path is not None:
+            ref_t = ref_flops_per_path * paths_per_launch / (kernel_ms * 1e-3) / 1e12
+            roofline["reference_work"] = {
+                "flops_per_path": round(ref_flops_per_path, 1), "TFLOP/s": round(ref_t, 3), "frac": round(ref_t / VALU_PEAK_TFLOPS, 4),
+                "source": ref_source,
+                "note": "secondary figure: the work the reference's own algorithm would do for these paths (unpruned BvhNode::hit "
+                        "with every Aabb::hit it makes) at this kernel's speed; the kernel does not execute that work"}
+
+    # main.rs:67-155 end to end on the device: render, tonemap, and the copy of the 8-bit image to the host
+    end_to_end = None
+    if rank == 0 and world == 1:
+        u8 = torch.empty(ny * nx * 3, dtype=torch.uint8, device=dev)
+        host = torch.empty(ny * nx * 3, dtype=torch.uint8).pin_memory()
+        ts = []
+        for _ in range(3):
+            torch.cuda.synchronize(dev)
+            c0 = time.perf_counter()
+            r.render_device(cam, params, bufs[0].data_ptr(), None, stream.cuda_stream)
+            r.tonemap_device(bufs[0].data_ptr(), nx, ny, spp, u8.data_ptr(), stream.cuda_stream)
+            host.copy_(u8, non_blocking=True)
+            torch.cuda.synchronize(dev)
+            ts.append(time.perf_counter() - c0)
+        end_to_end = {"seconds": round(sorted(ts)[1], 5), "what": "render + tonemap on the device + copy of the %d-byte 8-bit image "
+                      "to pinned host memory (main.rs:67-155), wall clock, median of 3" % (nx * ny * 3)}
+
+    other = None
+    if rank == 0 and world == 1 and not args.no_other_configs:
+        from bench_scenes import OTHER_CONFIGS, measure_config
+        other = []
+        for cfg in OTHER_CONFIGS:
+            try:
+                other.append(measure_config(cfg, device_index=local_rank, cpu=not args.no_cpu_baseline))
+            except Exception as e:  # a failed side configuration must not lose the headline line
+                other.append({"config": cfg["name"], "error": "%s: %s" % (type(e).__name__, e)})
 
     if rank == 0:
         paths = float(nx) * ny * spp * args.steps
@@ -247,8 +282,10 @@ def main():
                        "sharding": ("REHEARSAL: ranks share one GPU, gloo exchange" if args.rehearse_on_one_gpu else
                                     "sample range per GPU + RCCL reduce(sum) to rank 0" + (", overlapped with the next image's render" if overlap else "")) if world > 1 else "single GPU",
                        "seed": seed},
+            "sec_to_image_end_to_end": end_to_end,
             "roofline": roofline,
             "cpu_baseline": cpu,
+            "other_configs": other,
             "event_counts_rank0": counts,
             "image_checksum": image_checksum,
         }

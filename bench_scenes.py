@@ -45,6 +45,114 @@ def build(name, ratio, args):
     raise SystemExit("unknown scene " + name)
 
 
+# The named configurations of BASELINE.json other than the headline (bench.py's), as bench.py's `other_configs` runs them:
+# the configuration's own scene and frame, a sample count that keeps the default bench run short (throughput in paths/s
+# does not depend on it beyond the end-of-launch tail), and the bounded sample the CPU restatement is timed on.
+OTHER_CONFIGS = [
+    {"name": "C1 Book-1 random spheres 400x225 @ 16 spp", "scene": "random", "nx": 400, "ny": 225, "spp": 16,
+     "cpu": (400, 225, 256), "named_spp": 16},
+    {"name": "C3 Book-2 final scene 1920x1080 (named at 4096 spp)", "scene": "final", "nx": 1920, "ny": 1080, "spp": 256,
+     "cpu": (1920, 1080, 8), "named_spp": 4096},
+    {"name": "C4 2^20-sphere BVH stress 3840x2160 @ 64 spp", "scene": "stress", "nx": 3840, "ny": 2160, "spp": 64,
+     "cpu": (960, 540, 1), "named_spp": 64},
+    {"name": "C5 Cornell + glass sphere + smoke 7680x4320 (named at 16384 spp)", "scene": "smoke", "nx": 7680, "ny": 4320, "spp": 64,
+     "cpu": (1920, 1080, 64), "named_spp": 16384},
+]
+
+
+def measure_config(cfg, device_index=0, reps=3, cpu=True, spheres=1 << 20, seed=0x5EED0000):
+    """One entry of bench.py's `other_configs`: the production kernel timed with HIP events on its launch stream, the
+    event counts of the same launch from the counting build, the roofline on those counts, and the CPU restatement
+    (f64, the reference's 8-thread sample split) on a bounded sample of the same scene."""
+    import statistics
+    import torch
+    from raytracing_amd import Renderer, Scene, make_params
+    from bench import VALU_PEAK_TFLOPS, HBM_PEAK_GBS, algorithmic_flops
+
+    class _A(object):
+        pass
+    a = _A()
+    a.spheres = spheres
+    nx, ny, spp = cfg["nx"], cfg["ny"], cfg["spp"]
+    t0 = time.perf_counter()
+    sc = Scene(seed)
+    with sc:
+        cam, world, light, sky = build(cfg["scene"], float(nx) / ny, a)
+        if light is not None:
+            sc.light_xz_rect(*light)
+        flat = sc.flatten(world)
+    t_build = time.perf_counter() - t0
+    r = Renderer(device_index)
+    r.upload_scene(flat)
+    p = make_params(nx, ny, spp, sky=sky)
+    dev = torch.device("cuda", device_index)
+    buf = torch.empty(ny * nx * 3, dtype=torch.float32, device=dev)
+    stream = torch.cuda.current_stream(dev)
+    times = []
+    for k in range(reps + 1):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        r.render_device(cam, p, buf.data_ptr(), None, stream.cuda_stream)
+        e1.record(stream)
+        torch.cuda.synchronize(dev)
+        if k > 0:
+            times.append(e0.elapsed_time(e1))
+    ms = statistics.median(times)
+    checksum = float(buf.double().sum().item())
+    del buf
+    _, st = r.render(cam, p, want_stats=True)
+    r.close()
+    paths = float(nx) * ny * spp
+    flops = float(algorithmic_flops(st))
+    achieved = flops / (ms * 1e-3) / 1e12
+    out = {
+        "config": cfg["name"], "scene": cfg["scene"], "nx": nx, "ny": ny, "spp": spp, "named_spp": cfg["named_spp"],
+        "nodes": flat.n_nodes, "prims": flat.n_prims, "scene_build_s": round(t_build, 2),
+        "kernel_ms": round(ms, 3), "Mpaths_per_s": round(paths / ms / 1e3, 2), "Mrays_per_s": round(st.rays / ms / 1e3, 2),
+        "sec_to_image_at_named_spp": round(ms * 1e-3 * cfg["named_spp"] / spp, 4),
+        "rays_per_path": round(st.rays / paths, 3), "node_tests_per_ray": round(st.node_tests / float(st.rays), 2),
+        "image_checksum": checksum,
+        "roofline": {"bound": "valu", "kernel": "render_kernel", "achieved": round(achieved, 3), "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": round(achieved / VALU_PEAK_TFLOPS, 4), "flops_per_path": round(flops / paths, 1),
+                     "definition": "event counts of this launch (rt_stats) x the per-event constants of bench.py / kernel time"},
+    }
+    if cfg["scene"] == "stress":
+        # The traversal of this scene is the memory-side configuration: its fabric traffic comes from the committed PMC
+        # profile of this exact launch (bytes per launch do not depend on the run), divided by this run's kernel time.
+        tf = os.path.join(ROOT, "profiles", "r2", "stress_traffic.json")
+        mem = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "achieved": None, "frac": None, "traffic": None,
+               "request_bytes_per_launch": int(32 * st.node_tests + 20 * st.sphere_tests),
+               "note": "achieved = fabric read bytes per launch (FETCH_SIZE x 2, PMC profile of the same launch) / kernel time; "
+                       "request bytes (32 B per box test + 20 B per sphere test) are nearly all served by L1/L2 and are not traffic"}
+        if os.path.exists(tf):
+            t = json.load(open(tf))
+            if (t.get("nx"), t.get("ny"), t.get("spp")) == (nx, ny, spp):
+                mem["traffic"] = int(t["read_bytes"] + t.get("write_bytes", 0))
+                mem["achieved"] = round(mem["traffic"] / (ms * 1e-3) / 1e9, 1)
+                mem["frac"] = round(mem["achieved"] / HBM_PEAK_GBS, 4)
+        out["roofline_memory"] = mem
+    if cpu:
+        from oracle import binding as orc
+        cnx, cny, cspp = cfg["cpu"]
+        if cnx * ny == cny * nx:  # same aspect ratio: the same camera and scene
+            ccam, cflat, csky = cam, flat, sky
+        else:
+            sc2 = Scene(seed)
+            with sc2:
+                ccam, cworld, clight, csky = build(cfg["scene"], float(cnx) / cny, a)
+                if clight is not None:
+                    sc2.light_xz_rect(*clight)
+                cflat = sc2.flatten(cworld)
+        cp = make_params(cnx, cny, cspp, sky=csky)
+        c0 = time.perf_counter()
+        orc.render(cflat, ccam.c, cp, mode=orc.ORC_F64, n_threads=8, split_samples=cspp >= 8, want_sumsq=False)
+        dt = time.perf_counter() - c0
+        out["cpu_baseline"] = {"value": round(cnx * cny * cspp / dt / 1e6, 4), "unit": "Mpaths/s", "cores": 8, "kind": "port",
+                               "sample": "same scene at %dx%d, %d spp (%.1f s); f64 restatement of the reference algorithm on 8 threads "
+                                         "(main.rs:70), not the Rust binary" % (cnx, cny, cspp, dt)}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--scene", default="cornell")
