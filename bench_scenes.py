@@ -37,7 +37,9 @@ def build(name, ratio, args):
         cam, world = S.cornell_smoke_scene(ratio, smoke=True)
         return cam, world, S.SMOKE_LIGHT_SHAPE, 0
     if name == "final":
-        cam, world = S.final_scene(ratio)
+        # RT_FINAL_VARIANT=nomarble,nomedia: timing experiments on what those parts cost
+        v = os.environ.get("RT_FINAL_VARIANT", "")
+        cam, world = S.final_scene(ratio, marble="nomarble" not in v, media="nomedia" not in v)
         return cam, world, S.FINAL_LIGHT_SHAPE, 0
     if name == "stress":
         cam, world = S.sphere_stress_scene(ratio, args.spheres)

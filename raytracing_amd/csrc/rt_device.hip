@@ -35,6 +35,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -117,11 +118,16 @@ struct DevScene {
   // nodes with packed leaf information, and the objects their leaves refer to.  In
   // that mode `scan` holds only the ConstantMedium nodes, walked after the tree.
   const struct BNode* bnodes;
-  const struct BNode2* bnodes2;
+  const struct BNode4* bnodes4;
+  int root_ref;            // the world tree's root as a reference
+  const int* sub_root_ref;  // per object: the reference of an RT_OBJ_BVH's sub-tree root
+  const int* box6_index;   // per primitive: >= 0 where a list of six rects in Cuboid::new's order starts, the index of its record
+  const float4* box6_recs; // 5 float4 per record: the 18 floats of box6_test, padded
   const int* prim_rank;  // per primitive: depth-first rank of its leaf
   const rt_object* objects;
   int stack_mode;
-  int stack_depth;  // entries per lane of the traversal stack
+  int stack_depth;  // entries per lane of the traversal stack that the deepest walk can need
+  int stack_lds;    // of which this many live in LDS
   rt_light light;
 };
 
@@ -137,20 +143,24 @@ struct BNode {
   int right;
 };
 #define BN_INDEX_MASK 0x0fffffff
-// What the stack traversal fetches at an interior node: the boxes of its two
-// children and where they are, 64 bytes, so each fetch decides two box tests and
-// a leaf's box never costs a fetch of its own.  A child reference is the child's
-// index in the breadth-first array, with BN2_LEAF set when that child is a leaf;
-// a leaf of one primitive is referred to by the primitive's index instead.
-struct BNode2 {
-  float lmin[3]; int left;
-  float lmax[3]; int right;
-  float rmin[3]; float l_top;  // y_top of the children (see slab_core)
-  float rmax[3]; float r_top;
+// What the stack traversal fetches at an interior node, 128 bytes (one cache line): the boxes of up to four
+// descendants and where they are.  The binary tree of bvh.rs is collapsed two levels at a time on upload: a
+// node's entry holds its grandchildren (or a child itself where that child is a leaf).  Leaving out the box test
+// of the child in between changes no result: a box lies inside its parent's and the slab arithmetic is monotonic
+// in the bounds, so a ray that passes a node's Aabb::hit passes every ancestor's.  Half as many dependent
+// fetches per ray, each deciding four box tests.  A reference is an index into this array for an interior
+// descendant, the descendant's index in the breadth-first array with BN2_LEAF set for a leaf, and for a leaf of
+// one primitive the primitive's index; empty slots hold BN4_EMPTY and a box no ray passes.
+struct BNode4 {
+  float lox[4], loy[4], loz[4];
+  float hix[4], hiy[4], hiz[4];
+  int ref[4];
+  float top[4];  // y_top of each descendant (see slab_core)
 };
+static_assert(sizeof(BNode4) == 128, "one cache line");
 #define BN2_LEAF 0x40000000
 #define BN2_PRIM 0x20000000  // with BN2_LEAF: a single-primitive leaf, the low bits are the primitive's index
-#define BN2_INLINE 0x10000000  // with BN2_PRIM: test the primitive inside the descent loop (scenes whose leaves are all single primitives)
+#define BN4_EMPTY (-2)
 #define STACK_DEPTH 64  // deepest tree the stack traversal takes; the launch sizes the LDS stack to the scene's own depth
 #define STACK_RESTORE 0xffffffffu
 
@@ -616,15 +626,9 @@ __device__ __forceinline__ void scan_range(const DevScene& S, int begin, int end
   }
 }
 
-// Per-lane nearest hit over the breadth-first tree with a stack in LDS (one
-// column per lane).  Used for scenes too large for the wave-uniform scan: every
-// lane follows its own ray, nearer child first, pruning boxes entered beyond its
-// best hit.  The reference visits both children and lets the right one win an
-// exact tie (bvh.rs:204-217); visiting in another order gives the same winner
-// when a tie goes to the leaf that comes later in depth-first order, so every
-// primitive has the rank of its leaf in prim_rank[], read only on a tie.  A leaf that is a Translate/RotateY over a BvhNode pushes a
-// marker, switches the lane to the object's frame and descends; the marker
-// switches it back.
+// HitableList::hit (hitable.rs:105-117) over prims[first, first+count) as one lane of the stack traversal meets
+// it: per-lane loads, a per-lane loop.  An exact tie with the best hit so far goes to the leaf that comes later in
+// depth-first order (see trace_stack).
 template <bool STATS>
 __device__ __forceinline__ void prim_list_lane(const DevScene& S, int first, int count, const RayF& r, float t_min, float t_max, Hit& best,
                                                Counters& cnt) {
@@ -659,98 +663,188 @@ __device__ __forceinline__ void prim_list_lane(const DevScene& S, int first, int
   }
 }
 
+// A list of six rects in Cuboid::new's order, as one lane meets it in the stack traversal: the 18-float record of
+// box6_test read per lane (five 16-byte loads in flight together) and the same three pair tests, no loop and no dispatch.
 template <bool STATS>
-__device__ __forceinline__ void trace_stack(const DevScene& S, unsigned* __restrict__ stk, const RayF& w, float t_min, float t_max, Hit& best,
+__device__ __forceinline__ void box6_lane(const DevScene& S, int rec, int first, const RayF& r, float t_min, float t_max, Hit& best, Counters& cnt) {
+  const float4* src = (const float4*)((const char*)S.box6_recs + (unsigned)rec * 80u);
+  const float4 v0 = src[0], v1 = src[1], v2 = src[2], v3 = src[3], v4 = src[4];
+  const float g[18] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w, v3.x, v3.y, v3.z, v3.w, v4.x, v4.y};
+  float loc_t = t_max;
+  int loc_k = -1;
+  box_pair<2, 0, 1>(&g[0], 0, true, r, t_min, loc_t, loc_k);
+  box_pair<1, 0, 2>(&g[6], 2, true, r, t_min, loc_t, loc_k);
+  box_pair<0, 1, 2>(&g[12], 4, true, r, t_min, loc_t, loc_k);
+  if (STATS) cnt.rect_tests += 6u;
+  if (loc_k < 0) return;
+  const int loc_prim = first + loc_k;
+  bool take = loc_t < best.t;
+  if (!take && !(best.t < loc_t)) take = best.prim < 0 || S.prim_rank[loc_prim] > S.prim_rank[best.prim];
+  if (take) {
+    best.t = loc_t;
+    best.prim = loc_prim;
+  }
+}
+template <bool STATS>
+__device__ __forceinline__ void leaf_list_lane(const DevScene& S, int first, int count, const RayF& r, float t_min, float t_max, Hit& best, Counters& cnt) {
+  int rec = -1;
+  if (count == 6) rec = S.box6_index[first];
+  if (rec >= 0) box6_lane<STATS>(S, rec, first, r, t_min, t_max, best, cnt);
+  else prim_list_lane<STATS>(S, first, count, r, t_min, t_max, best, cnt);
+}
+
+// The lane's stack: the first S.stack_lds entries of a lane live in LDS (one column per lane, consecutive entries 64
+// dwords apart), deeper ones in the lane's private memory.  The LDS part decides how many waves fit on a CU, and the
+// depth a walk can reach in the worst case (every box of every level entered) is several times what walks reach in
+// practice, so LDS holds what is used and the rest exists for safety.
+#define RT_STACK_PRIVATE 64
+#ifndef RT_STACK_LDS
+#define RT_STACK_LDS 16
+#endif
+struct LaneStack {
+  unsigned* lds;  // this lane's column
+  int n_lds;      // entries in LDS
+  unsigned deep[RT_STACK_PRIVATE];
+  __device__ __forceinline__ void put(int at, unsigned v) {
+    if (at < n_lds) lds[at * 64] = v;
+    else deep[at - n_lds] = v;
+  }
+  __device__ __forceinline__ unsigned get(int at) const { return at < n_lds ? lds[at * 64] : deep[at - n_lds]; }
+};
+
+// The state of one lane's walk through the four-wide tree.
+struct Trav {
+  RayF r;    // the ray in the frame of the sub-tree the lane is in
+  int sp;    // entries on the lane's stack
+  int cur;   // the reference to look at next, or TRAV_POP
+  Hit best;
+};
+#define TRAV_POP (-1)
+// True while `cur` is a list or instance leaf: the lane waits for the wave's leaf code.
+__device__ __forceinline__ bool trav_holds_leaf(int cur) { return (cur != TRAV_POP) & ((cur & BN2_LEAF) != 0); }
+
+// The root's own box (bvh.rs:198), then the root as a reference.  `ref` is the root's reference, `box` its node.
+template <bool STATS>
+__device__ __forceinline__ int trav_enter(const DevScene& S, int ref, int box, const RayF& r, float t_min, float t_max, Counters& cnt) {
+  const float4 lo = *(const float4*)&S.bnodes[box];
+  const float4 hi = *((const float4*)&S.bnodes[box] + 1);
+  float te;
+  if (STATS) cnt.node_tests++;
+  // nothing to prune against yet at the world root; inside an object the root gets the box test only, as the first node of a BvhNode::hit
+  const bool h = slab_box_enter(lo, hi, hi.y, r, ray_signs(r), t_min, t_max, 3.402823466e+38f, te);
+  return h ? ref : TRAV_POP;
+}
+
+// One step of a lane that is not holding a leaf: pop if there is nothing to look at, then fetch a four-wide node,
+// test its boxes and go to the nearest descendant the ray enters, pushing the others farthest first.  Returns false
+// when the walk has ended.  (Leaves, single primitives included, are left to trav_leaf: the wave runs that code for
+// many lanes at once, which was measured faster than testing a primitive where a lane meets it.)
+template <bool STATS>
+__device__ __forceinline__ bool trav_step(const DevScene& S, LaneStack& stk, Trav& T, const RayF& w, float t_min, float t_max, Counters& cnt) {
+  if (T.cur == TRAV_POP) {
+    if (T.sp == 0) return false;
+    --T.sp;
+    const unsigned x = stk.get(T.sp);
+    if (x == STACK_RESTORE) {
+      T.r = w;
+      return true;
+    }
+    T.cur = (int)x;
+  }
+  const int cur = T.cur;
+  if (cur & BN2_LEAF) return true;  // (a leaf popped from the stack: the lane now holds it)
+  // base + 32-bit byte offset: the loads take the array's address from scalar registers and one shifted index per lane
+  const float4* rec = (const float4*)((const char*)S.bnodes4 + ((unsigned)cur << 7));
+  const float4 lox = rec[0], loy = rec[1], loz = rec[2], hix = rec[3], hiy = rec[4], hiz = rec[5], refs_f = rec[6], top = rec[7];
+  const Signs sg = ray_signs(T.r);
+  float t0, t1, t2, t3;
+  const bool h0 = slab_core(lox.x, loy.x, loz.x, hix.x, hiy.x, hiz.x, top.x, T.r, sg, t_min, t_max, T.best.t, t0);
+  const bool h1 = slab_core(lox.y, loy.y, loz.y, hix.y, hiy.y, hiz.y, top.y, T.r, sg, t_min, t_max, T.best.t, t1);
+  const bool h2 = slab_core(lox.z, loy.z, loz.z, hix.z, hiy.z, hiz.z, top.z, T.r, sg, t_min, t_max, T.best.t, t2);
+  const bool h3 = slab_core(lox.w, loy.w, loz.w, hix.w, hiy.w, hiz.w, top.w, T.r, sg, t_min, t_max, T.best.t, t3);
+  const int r0 = __float_as_int(refs_f.x), r1 = __float_as_int(refs_f.y), r2 = __float_as_int(refs_f.z), r3 = __float_as_int(refs_f.w);
+  if (STATS) cnt.node_tests += 2u + (r2 != BN4_EMPTY) + (r3 != BN4_EMPTY);
+  // Order by entry distance: the distance (not negative, so its bits order like an integer) with its two lowest bits
+  // replaced by the slot number is one sortable key per descendant; a miss sorts last.  Which of two equally near
+  // boxes comes first does not matter: the winner is decided by t and, on an exact tie, by leaf rank.
+  unsigned k0 = h0 ? ((__float_as_uint(t0) & ~3u) | 0u) : 0xffffffffu;
+  unsigned k1 = h1 ? ((__float_as_uint(t1) & ~3u) | 1u) : 0xffffffffu;
+  unsigned k2 = h2 ? ((__float_as_uint(t2) & ~3u) | 2u) : 0xffffffffu;
+  unsigned k3 = h3 ? ((__float_as_uint(t3) & ~3u) | 3u) : 0xffffffffu;
+  unsigned lo_, hi_;
+  lo_ = min(k0, k1); hi_ = max(k0, k1); k0 = lo_; k1 = hi_;
+  lo_ = min(k2, k3); hi_ = max(k2, k3); k2 = lo_; k3 = hi_;
+  lo_ = min(k0, k2); hi_ = max(k0, k2); k0 = lo_; k2 = hi_;
+  lo_ = min(k1, k3); hi_ = max(k1, k3); k1 = lo_; k3 = hi_;
+  lo_ = min(k1, k2); hi_ = max(k1, k2); k1 = lo_; k2 = hi_;
+  const int n_hit = (int)h0 + (int)h1 + (int)h2 + (int)h3;
+#define RT_REF_OF(k) (((k) & 2u) ? (((k) & 1u) ? r3 : r2) : (((k) & 1u) ? r1 : r0))
+  if (n_hit >= 4) { stk.put(T.sp, (unsigned)RT_REF_OF(k3)); ++T.sp; }
+  if (n_hit >= 3) { stk.put(T.sp, (unsigned)RT_REF_OF(k2)); ++T.sp; }
+  if (n_hit >= 2) { stk.put(T.sp, (unsigned)RT_REF_OF(k1)); ++T.sp; }
+  T.cur = n_hit >= 1 ? RT_REF_OF(k0) : TRAV_POP;
+#undef RT_REF_OF
+  return true;
+}
+
+// The leaf a lane holds (its box has been passed): a primitive list in the current frame, or an object:
+// Translate/RotateY over a list or over a BvhNode, whose sub-tree the lane enters in the object's frame with a
+// marker on the stack that switches it back.  ConstantMedium leaves are left to the caller (they draw random numbers).
+template <bool STATS>
+__device__ __forceinline__ void trav_leaf(const DevScene& S, LaneStack& stk, Trav& T, const RayF& w, float t_min, float t_max, Counters& cnt) {
+  const int node = T.cur & BN_INDEX_MASK;
+  const bool single = (T.cur & BN2_PRIM) != 0;
+  T.cur = TRAV_POP;
+  int ref = node, count = 1;
+  if (!single) {
+    ref = ~S.bnodes[node].left;
+    count = S.bnodes[node].right;
+  }
+  if (count > 0) {
+    if (single) prim_list_lane<STATS>(S, ref, 1, T.r, t_min, t_max, T.best, cnt);
+    else leaf_list_lane<STATS>(S, ref, count, T.r, t_min, t_max, T.best, cnt);
+    return;
+  }
+  const rt_object ob = S.objects[ref];
+  if (ob.kind == RT_OBJ_MEDIUM) return;
+  const RayF q = to_object_frame<true>(w, ob.xform, ob.sin_theta, ob.cos_theta, ob.offset[0], ob.offset[1], ob.offset[2]);
+  if (STATS) cnt.instance_ops++;
+  if (ob.kind == RT_OBJ_LIST) {
+    leaf_list_lane<STATS>(S, ob.first, ob.count, q, t_min, t_max, T.best, cnt);
+  } else {
+    stk.put(T.sp, STACK_RESTORE);
+    ++T.sp;
+    T.r = q;
+    T.cur = trav_enter<STATS>(S, S.sub_root_ref[ref], ob.first, T.r, t_min, t_max, cnt);
+  }
+}
+
+// Per-lane nearest hit over the four-wide tree with a stack in LDS (one column per lane; consecutive entries
+// are 64 dwords apart).  Used for scenes too large for the wave-uniform scan: every lane follows its own ray,
+// nearer boxes first, skipping boxes entered beyond its best hit.  The reference visits both children and lets the
+// right one win an exact tie (bvh.rs:204-217); visiting in another order gives the same winner when a tie goes to
+// the leaf that comes later in depth-first order, so every primitive has the rank of its leaf in prim_rank[],
+// read only on a tie.
+template <bool STATS>
+__device__ __forceinline__ void trace_stack(const DevScene& S, unsigned* __restrict__ stk_lds, const RayF& w, float t_min, float t_max, Hit& best,
                                             Counters& cnt) {
-  // stk points at this lane's column; consecutive entries are 64 dwords apart.
-  const int POP = -1;
-  RayF r = w;
-  Signs sg = ray_signs(r);
-  int sp = 0;
-  // the root's own box (bvh.rs:198), then the root as a reference
-  int cur;
-  {
-    const float4 lo = *(const float4*)&S.bnodes[0];
-    const float4 hi = *((const float4*)&S.bnodes[0] + 1);
-    float te;
-    if (STATS) cnt.node_tests++;
-    const bool h = slab_box_enter(lo, hi, hi.y, r, sg, t_min, t_max, 3.402823466e+38f, te);  // nothing to prune against yet
-    cur = h ? (S.bnodes[0].left < 0 ? BN2_LEAF : 0) : POP;
-  }
+  LaneStack stk;
+  stk.lds = stk_lds;
+  stk.n_lds = S.stack_lds;
+  Trav T;
+  T.r = w;
+  T.sp = 0;
+  T.best = best;
+  T.cur = trav_enter<STATS>(S, S.root_ref, 0, w, t_min, t_max, cnt);
   for (;;) {
-    // down through interior nodes until this lane holds a leaf (lanes that have one wait for the rest of the wave,
-    // so the leaf code below runs once for many lanes instead of once per step)
-    for (;;) {
-      if (cur == POP) {
-        if (sp == 0) break;
-        --sp;
-        const unsigned x = stk[sp * 64];
-        if (x == STACK_RESTORE) {
-          r = w;
-          sg = ray_signs(r);
-          continue;
-        }
-        cur = (int)x;
-      }
-      if (cur & BN2_LEAF) {
-        if (!(cur & BN2_INLINE)) break;
-        // every leaf of this scene is one primitive: cheap enough to test in step with the other lanes' interior nodes
-        prim_list_lane<STATS>(S, cur & BN_INDEX_MASK, 1, r, t_min, t_max, best, cnt);
-        cur = POP;
-        continue;
-      }
-      // interior: both children's boxes from one 64-byte record
-      // base + 32-bit byte offset: the loads take the array's address from scalar registers and one shifted index per lane
-      const float4* rec = (const float4*)((const char*)S.bnodes2 + ((unsigned)cur << 6));
-      const float4 llo = rec[0], lhi = rec[1], rlo = rec[2], rhi = rec[3];
-      float tl, tr;
-      const bool hl = slab_box_enter(llo, lhi, rlo.w, r, sg, t_min, t_max, best.t, tl);  // the spare words hold the children's y_top
-      const bool hr = slab_box_enter(rlo, rhi, rhi.w, r, sg, t_min, t_max, best.t, tr);
-      if (STATS) cnt.node_tests += 2;
-      const int left = __float_as_int(llo.w), right = __float_as_int(lhi.w);
-      const bool left_first = !(tr < tl);
-      if (hl & hr) {
-        stk[sp * 64] = (unsigned)(left_first ? right : left);
-        ++sp;
-        cur = left_first ? left : right;
-      } else {
-        cur = hl ? left : (hr ? right : POP);
-      }
-    }
-    if (cur == POP) break;
-    // a leaf whose box the ray has passed
-    const int node = cur & BN_INDEX_MASK;
-    const bool single = (cur & BN2_PRIM) != 0;
-    cur = POP;
-    int ref = node, count = 1;
-    if (!single) {
-      ref = ~S.bnodes[node].left;
-      count = S.bnodes[node].right;
-    }
-    if (count > 0) {
-      prim_list_lane<STATS>(S, ref, count, r, t_min, t_max, best, cnt);
-      continue;
-    }
-    const rt_object ob = S.objects[ref];
-    if (ob.kind == RT_OBJ_MEDIUM) continue;  // walked separately: it needs random numbers
-    const RayF q = to_object_frame<true>(w, ob.xform, ob.sin_theta, ob.cos_theta, ob.offset[0], ob.offset[1], ob.offset[2]);
-    if (STATS) cnt.instance_ops++;
-    if (ob.kind == RT_OBJ_LIST) {
-      prim_list_lane<STATS>(S, ob.first, ob.count, q, t_min, t_max, best, cnt);
-    } else {
-      // a BvhNode under Translate/RotateY: its root box in the object's frame, then down
-      stk[sp * 64] = STACK_RESTORE;
-      ++sp;
-      r = q;
-      sg = ray_signs(r);
-      const float4 lo = *(const float4*)&S.bnodes[ob.first];
-      const float4 hi = *((const float4*)&S.bnodes[ob.first] + 1);
-      float te;
-      if (STATS) cnt.node_tests++;
-      const bool h = slab_box_enter(lo, hi, hi.y, r, sg, t_min, t_max, 3.402823466e+38f, te);  // the sub-tree's root: box test only
-      cur = h ? (ob.first | (S.bnodes[ob.first].left < 0 ? BN2_LEAF : 0)) : POP;
-    }
+    // down until this lane holds a list or instance leaf (lanes that have one wait for the rest of the wave,
+    // so the leaf code runs once for many lanes instead of once per step)
+    bool more = true;
+    while (more && !trav_holds_leaf(T.cur)) more = trav_step<STATS>(S, stk, T, w, t_min, t_max, cnt);
+    if (!more) break;
+    trav_leaf<STATS>(S, stk, T, w, t_min, t_max, cnt);
   }
+  best = T.best;
 }
 
 // Nearest hit of BvhNode::hit (bvh.rs:197-228).  Must be called by all 64 lanes.
@@ -840,8 +934,8 @@ template <int TRAV>
 __global__ void __launch_bounds__(256) trace_kernel(DevScene S, const float* __restrict__ o, const float* __restrict__ d, size_t n,
                                                     float t_min, float t_max, int* __restrict__ prim_id, float* __restrict__ t_out,
                                                     float* __restrict__ normal, float* __restrict__ p_out) {
-  extern __shared__ unsigned trace_stack_lds[];  // TRAV_STACK: stack_depth entries of 64 lanes for each of the 4 waves
-  unsigned* stk = trace_stack_lds + (TRAV == TRAV_STACK ? (threadIdx.x >> 6) * S.stack_depth * 64 : 0) + (threadIdx.x & 63);
+  extern __shared__ unsigned trace_stack_lds[];  // TRAV_STACK: stack_lds entries of 64 lanes for each of the 4 waves
+  unsigned* stk = trace_stack_lds + (TRAV == TRAV_STACK ? (threadIdx.x >> 6) * S.stack_lds * 64 : 0) + (threadIdx.x & 63);
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   // Whole waves stay in the loop together: the traversal uses wave-wide operations.
   const size_t n_round = (n + 63) / 64 * 64;
@@ -955,6 +1049,179 @@ __device__ __forceinline__ F3 reflect3(F3 v, F3 n) {
   return f3(v.x - k * n.x, v.y - k * n.y, v.z - k * n.z);
 }
 
+#define RT_INV_PI_F 0.31830988618379067154f
+
+// What one path vertex comes to: color() of main.rs:165-209 for the hit `h` of `ray`.
+struct Shaded {
+  F3 radiance;  // what this vertex adds to the sample (weight x emitted or sky), before de_nan
+  F3 dir;       // direction of the ray that continues the path (not normalised, as in the source)
+  F3 thr_next;  // the path's weight after this vertex
+  F3 p;         // the hit point
+  bool scattered, textured, emits;
+  int mat_index;
+};
+// Every lane runs it; dead lanes and misses work on primitive 0 with their results masked by the caller.  `w` is the
+// Philox call of this vertex.
+template <bool STATS, int GENERAL>
+__device__ __forceinline__ Shaded shade_vertex(const DevScene& S, const float4* dprim_tab, bool alive, const Hit& h, const RayF& ray, F3 thr,
+                                               int depth, const U4& w, int a_max_depth, int a_sky, unsigned pixel_id, unsigned sample,
+                                               unsigned key0, unsigned key1, Counters& cnt) {
+  Shaded out;
+  // ---- color(), main.rs:165-209, one vertex; every lane runs it, dead lanes and
+  // misses on primitive 0 with their results masked ----
+  const bool hit = alive & (h.prim >= 0);
+  DevPrim q;
+  {
+    const float4* src = (const float4*)((const char*)dprim_tab + ((unsigned)(hit ? h.prim : 0) << 6));
+    const float4 q0 = src[0], q1 = src[1], q2 = src[2], q3 = src[3];
+    __builtin_memcpy((char*)&q, &q0, 16);
+    __builtin_memcpy((char*)&q + 16, &q1, 16);
+    __builtin_memcpy((char*)&q + 32, &q2, 16);
+    __builtin_memcpy((char*)&q + 48, &q3, 16);
+  }
+  const Surface sf = finalize_hit(q, ray, h.t, S.has_spheres != 0);
+  const int mat_type = (q.flags >> DP_MAT_SHIFT) & 7;
+  F3 color = f3(q.color[0], q.color[1], q.color[2]);
+  if (STATS) cnt.hits += hit;
+  // A checker or noise texture's colour comes at the top of the next trip (see there); until then it counts as white.
+  const bool textured = GENERAL == 2 && S.textured && hit && (q.flags & DP_TEXTURED);
+  if (GENERAL == 2) color = sel3(textured, f3(1.0f, 1.0f, 1.0f), color);
+
+  // material.rs:197-203: a light emits towards the side its normal points to and never scatters.
+  const bool is_light = mat_type == RT_MAT_DIFFUSE_LIGHT;
+  const bool emits = hit & is_light & (dot3(sf.normal, ray.d) < 0.0f);
+  // main.rs:203-208
+  F3 sky = f3(0, 0, 0);
+  if (a_sky == RT_SKY_GRADIENT) {
+    const F3 ud = unit3(ray.d);
+    const float t = 0.5f * (ud.y + 1.0f);
+    sky = f3((1.0f - t) + t * 0.5f, (1.0f - t) + t * 0.7f, (1.0f - t) + t * 1.0f);
+  }
+  const F3 le = sel3(emits, (GENERAL == 2) ? sel3(textured, f3(0, 0, 0), color) : color, sel3(hit, f3(0, 0, 0), sky));
+  out.radiance = f3(thr.x * le.x, thr.y * le.y, thr.z * le.z);  // what this vertex adds to the sample, before de_nan
+
+  // Lambertian under MixturePDF(HitablePDF(light), CosinePDF(normal)), main.rs:173-197.
+  const bool scatters = hit & (mat_type == RT_MAT_LAMBERTIAN) & (depth < a_max_depth);
+  if (STATS) cnt.shade_events += scatters;
+  const float xi1 = u01(w.z), xi2 = u01(w.w);
+  // onb.rs:10-21.  The normal is already of unit length (to rounding), and the cross
+  // product with an axis vector is written out: w x (0,1,0) = (-w.z, 0, w.x),
+  // w x (1,0,0) = (0, w.z, -w.y).
+  const F3 ww = sf.normal;
+  const bool big_x = fabsf(ww.x) > 0.9f;
+  const float other = big_x ? ww.x : ww.y;
+  const float inv_v = fast_rsq(fmaf(ww.z, ww.z, other * other));
+  const F3 vv = f3(big_x ? -ww.z * inv_v : 0.0f, big_x ? 0.0f : ww.z * inv_v, big_x ? ww.x * inv_v : -ww.y * inv_v);
+  const F3 uu = cross3(ww, vv);
+  const bool pick_light = (S.n_lights > 0) & ((w.y >> 31) != 0u);  // MixturePDF's coin, pdf.rs:70
+  // XZRect::random, hitable.rs:256-264
+  const F3 dir_light = f3(fmaf(xi1, S.light.f[1] - S.light.f[0], S.light.f[0]) - sf.p.x, S.light.f[4] - sf.p.y,
+                          fmaf(xi2, S.light.f[3] - S.light.f[2], S.light.f[2]) - sf.p.z);
+  // random_cosine_direction, main.rs:239-249 (x and y keep the source's factor 2);
+  // v_sin/v_cos take their argument in turns, so phi = 2*pi*r1 is r1 turns.
+  const float cz = fast_sqrt(1.0f - xi2);
+  const float r2s = 2.0f * fast_sqrt(xi2);
+  const float cx = __builtin_amdgcn_cosf(xi1) * r2s;
+  const float cy = __builtin_amdgcn_sinf(xi1) * r2s;
+  const F3 dir_cos = f3(fmaf(cz, ww.x, fmaf(cy, vv.x, cx * uu.x)), fmaf(cz, ww.y, fmaf(cy, vv.y, cx * uu.y)), fmaf(cz, ww.z, fmaf(cy, vv.z, cx * uu.z)));
+  F3 dir = sel3(pick_light, dir_light, dir_cos);
+  const float dlen2 = dot3(dir, dir);
+  const float inv_len = fast_rsq(dlen2);
+  // pdf.rs:19-26
+  const float cos_w = dot3(dir, ww) * inv_len;
+  float pdf_val = cos_w > 0.0f ? cos_w * RT_INV_PI_F : 0.0f;
+  if (S.n_lights > 0) {
+    // XZRect::pdf_value, hitable.rs:245-254 (its hit test uses 0.001 and f64::MAX)
+    if (STATS) cnt.light_tests += scatters;
+    const float t = (S.light.f[4] - sf.p.y) * fast_rcp(dir.y);
+    const float lx = fmaf(t, dir.x, sf.p.x), lz = fmaf(t, dir.z, sf.p.z);
+    const bool miss = (t < 0.001f) | (t > 3.402823466e+38f) | (lx < S.light.f[0]) | (lx > S.light.f[1]) | (lz < S.light.f[2]) | (lz > S.light.f[3]);
+    const float area = (S.light.f[1] - S.light.f[0]) * (S.light.f[3] - S.light.f[2]);
+    const float cosine = fabsf(dir.y * inv_len);
+    const float lp = miss ? 0.0f : (t * t * dlen2) * fast_rcp(cosine * area);
+    pdf_val = 0.5f * lp + 0.5f * pdf_val;
+  }
+  // material.rs:76-82
+  const float cos_n = fmaxf(dot3(sf.normal, dir) * inv_len, 0.0f);
+  const float f = (cos_n * RT_INV_PI_F) * fast_rcp(pdf_val);
+  F3 thr_next = f3(thr.x * color.x * f, thr.y * color.y * f, thr.z * color.z * f);
+  bool scattered = scatters;
+  if (GENERAL && (S.mat_mask & ((1 << RT_MAT_METAL) | (1 << RT_MAT_DIELECTRIC) | (1 << RT_MAT_ISOTROPIC)))) {
+    // Materials of the reference's older scatter() -> (attenuation, ray) form
+    // (material.rs:100-112, 125-159, 217-221, commented out there): the path goes on
+    // along the returned ray weighted by the attenuation, with no pdf involved.
+    const bool deep = depth < a_max_depth;
+    const bool is_metal = hit & deep & (mat_type == RT_MAT_METAL);
+    const bool is_diel = hit & deep & (mat_type == RT_MAT_DIELECTRIC);
+    const bool is_iso = hit & deep & (mat_type == RT_MAT_ISOTROPIC);
+    if (__ballot(is_metal | is_diel | is_iso) != 0ull) {
+      // random_in_unit_sphere (main.rs:211-221): attempt a draws counter (pixel, sample, depth, 256+a)
+      F3 rs = f3(0, 0, 0);
+      bool looking = is_metal | is_iso;
+      unsigned attempt = 0;
+#ifdef RT_HACK_DIRECT_BALL
+      {
+        const U4 sw = philox4x32_10(pixel_id, sample, (unsigned)depth, 256u + attempt, key0, key1);
+        const float cz = 1.0f - 2.0f * u01(sw.x);
+        const float sz = fast_sqrt(fmaxf(0.0f, 1.0f - cz * cz));
+        const float rad = __builtin_amdgcn_exp2f(__builtin_amdgcn_logf(u01(sw.z)) * (1.0f / 3.0f));
+        rs = f3(rad * sz * __builtin_amdgcn_cosf(u01(sw.y)), rad * sz * __builtin_amdgcn_sinf(u01(sw.y)), rad * cz);
+        looking = false;
+      }
+#endif
+      while (__ballot(looking) != 0ull) {
+        const U4 sw = philox4x32_10(pixel_id, sample, (unsigned)depth, 256u + attempt, key0, key1);
+        const F3 c = f3(2.0f * u01(sw.x) - 1.0f, 2.0f * u01(sw.y) - 1.0f, 2.0f * u01(sw.z) - 1.0f);
+        const bool ok = looking & (dot3(c, c) < 1.0f);
+        rs = sel3(ok, c, rs);
+        looking &= !ok;
+        ++attempt;
+      }
+      const F3 n = sf.normal;
+      // Metal::scatter
+      const F3 refl_unit = reflect3(unit3(ray.d), n);
+      const F3 m_dir = f3(refl_unit.x + q.fuzz * rs.x, refl_unit.y + q.fuzz * rs.y, refl_unit.z + q.fuzz * rs.z);
+      const bool m_ok = dot3(m_dir, n) > 0.0f;
+      // Dielectric::scatter (reflects the un-normalised incoming direction, material.rs:126)
+      const F3 reflected = reflect3(ray.d, n);
+      const float dn = dot3(ray.d, n);
+      const float d_len = fast_sqrt(dot3(ray.d, ray.d));
+      const bool outside = !(dn > 0.0f);
+      const F3 on_ = outside ? n : f3(-n.x, -n.y, -n.z);
+      const float ni_over_nt = outside ? fast_rcp(q.ref_idx) : q.ref_idx;
+      const float cosine = outside ? -dn * fast_rcp(d_len) : q.ref_idx * dn * fast_rcp(d_len);
+      const F3 uvd = unit3(ray.d);
+      const float dt = dot3(uvd, on_);
+      const float disc = 1.0f - ni_over_nt * ni_over_nt * (1.0f - dt * dt);
+      const float sq = fast_sqrt(disc);
+      const F3 refracted = f3(ni_over_nt * (uvd.x - on_.x * dt) - on_.x * sq, ni_over_nt * (uvd.y - on_.y * dt) - on_.y * sq,
+                              ni_over_nt * (uvd.z - on_.z * dt) - on_.z * sq);
+      float r0 = (1.0f - q.ref_idx) * fast_rcp(1.0f + q.ref_idx);
+      r0 = r0 * r0;
+      const float om = 1.0f - cosine;
+      const float reflect_prob = disc > 0.0f ? r0 + (1.0f - r0) * (om * om) * (om * om) * om : 1.0f;
+      const float xi = u01(w.y << 1);
+      const F3 d_dir = xi < reflect_prob ? reflected : refracted;
+      // Isotropic::scatter
+      const F3 s_dir = is_metal ? m_dir : (is_diel ? d_dir : rs);
+      const F3 atten = is_diel ? f3(1.0f, 1.0f, 1.0f) : color;
+      const bool s_any = is_metal | is_diel | is_iso;
+      const bool s_ok = (is_metal & m_ok) | is_diel | is_iso;
+      dir = sel3(s_any, s_dir, dir);
+      thr_next = sel3(s_any, f3(thr.x * atten.x, thr.y * atten.y, thr.z * atten.z), thr_next);
+      scattered = s_any ? s_ok : scattered;
+    }
+  }
+  out.dir = dir;
+  out.thr_next = thr_next;
+  out.p = sf.p;
+  out.scattered = scattered;
+  out.textured = textured;
+  out.emits = emits;
+  out.mat_index = q.flags >> DP_INDEX_SHIFT;
+  return out;
+}
+
 struct RenderArgs {
   int nx, ny, spp, sample_begin, max_depth, sky;
   float t_min, inv_nx, inv_ny;
@@ -964,6 +1231,8 @@ struct RenderArgs {
   int tiles_x, tiles_y;
   int n_chunks, chunk_spp;  // the samples of a tile are split into n_chunks work items of chunk_spp samples,
   int split_parts;          // the last of which is cut into this many parts, each half the one before
+  int ready_lanes;          // render_stack_kernel: finished rays in a wave (in 64 live ones) that end a traversal phase
+  int hold_lanes;           // and lanes holding a leaf (in 64 traversing ones) that make the wave run the leaf code
 };
 
 // Waves per SIMD the register allocator must leave room for (launch_bounds' second argument).
@@ -971,7 +1240,6 @@ struct RenderArgs {
 #define RT_RENDER_WAVES_PER_SIMD 7
 #endif
 
-#define RT_INV_PI_F 0.31830988618379067154f
 
 // ---------------------------------------------------------------------------
 // render_kernel
@@ -1193,141 +1461,10 @@ __global__ void __launch_bounds__(64, (TRAV == TRAV_STACK && GENERAL != 2) ? 6 :
     const PathRng rng = {pixel_id, sample, (unsigned)depth, key0, key1};
     const Hit h = trace_scan<STATS, TRAV, GENERAL != 0>(S, stk, box_tab, alive, ray, a_t_min, INFINITY, rng, cnt);
 
-    // ---- color(), main.rs:165-209, one vertex; every lane runs it, dead lanes and
-    // misses on primitive 0 with their results masked ----
-    const bool hit = alive & (h.prim >= 0);
-    DevPrim q;
-    {
-      const float4* src = (const float4*)((const char*)dprim_tab + ((unsigned)(hit ? h.prim : 0) << 6));
-      const float4 q0 = src[0], q1 = src[1], q2 = src[2], q3 = src[3];
-      __builtin_memcpy((char*)&q, &q0, 16);
-      __builtin_memcpy((char*)&q + 16, &q1, 16);
-      __builtin_memcpy((char*)&q + 32, &q2, 16);
-      __builtin_memcpy((char*)&q + 48, &q3, 16);
-    }
-    const Surface sf = finalize_hit(q, ray, h.t, S.has_spheres != 0);
-    const int mat_type = (q.flags >> DP_MAT_SHIFT) & 7;
-    F3 color = f3(q.color[0], q.color[1], q.color[2]);
-    if (STATS) cnt.hits += hit;
-    // A checker or noise texture's colour comes at the top of the next trip (see there); until then it counts as white.
-    const bool textured = GENERAL == 2 && S.textured && hit && (q.flags & DP_TEXTURED);
-    if (GENERAL == 2) color = sel3(textured, f3(1.0f, 1.0f, 1.0f), color);
-
-    // material.rs:197-203: a light emits towards the side its normal points to and never scatters.
-    const bool is_light = mat_type == RT_MAT_DIFFUSE_LIGHT;
-    const bool emits = hit & is_light & (dot3(sf.normal, ray.d) < 0.0f);
-    // main.rs:203-208
-    F3 sky = f3(0, 0, 0);
-    if (a_sky == RT_SKY_GRADIENT) {
-      const F3 ud = unit3(ray.d);
-      const float t = 0.5f * (ud.y + 1.0f);
-      sky = f3((1.0f - t) + t * 0.5f, (1.0f - t) + t * 0.7f, (1.0f - t) + t * 1.0f);
-    }
-    const F3 le = sel3(emits, (GENERAL == 2) ? sel3(textured, f3(0, 0, 0), color) : color, sel3(hit, f3(0, 0, 0), sky));
-    const F3 radiance = f3(thr.x * le.x, thr.y * le.y, thr.z * le.z);  // what this vertex adds to the sample, before de_nan
-
-    // Lambertian under MixturePDF(HitablePDF(light), CosinePDF(normal)), main.rs:173-197.
-    const bool scatters = hit & (mat_type == RT_MAT_LAMBERTIAN) & (depth < a_max_depth);
-    if (STATS) cnt.shade_events += scatters;
-    const float xi1 = u01(w.z), xi2 = u01(w.w);
-    // onb.rs:10-21.  The normal is already of unit length (to rounding), and the cross
-    // product with an axis vector is written out: w x (0,1,0) = (-w.z, 0, w.x),
-    // w x (1,0,0) = (0, w.z, -w.y).
-    const F3 ww = sf.normal;
-    const bool big_x = fabsf(ww.x) > 0.9f;
-    const float other = big_x ? ww.x : ww.y;
-    const float inv_v = fast_rsq(fmaf(ww.z, ww.z, other * other));
-    const F3 vv = f3(big_x ? -ww.z * inv_v : 0.0f, big_x ? 0.0f : ww.z * inv_v, big_x ? ww.x * inv_v : -ww.y * inv_v);
-    const F3 uu = cross3(ww, vv);
-    const bool pick_light = (S.n_lights > 0) & ((w.y >> 31) != 0u);  // MixturePDF's coin, pdf.rs:70
-    // XZRect::random, hitable.rs:256-264
-    const F3 dir_light = f3(fmaf(xi1, S.light.f[1] - S.light.f[0], S.light.f[0]) - sf.p.x, S.light.f[4] - sf.p.y,
-                            fmaf(xi2, S.light.f[3] - S.light.f[2], S.light.f[2]) - sf.p.z);
-    // random_cosine_direction, main.rs:239-249 (x and y keep the source's factor 2);
-    // v_sin/v_cos take their argument in turns, so phi = 2*pi*r1 is r1 turns.
-    const float cz = fast_sqrt(1.0f - xi2);
-    const float r2s = 2.0f * fast_sqrt(xi2);
-    const float cx = __builtin_amdgcn_cosf(xi1) * r2s;
-    const float cy = __builtin_amdgcn_sinf(xi1) * r2s;
-    const F3 dir_cos = f3(fmaf(cz, ww.x, fmaf(cy, vv.x, cx * uu.x)), fmaf(cz, ww.y, fmaf(cy, vv.y, cx * uu.y)), fmaf(cz, ww.z, fmaf(cy, vv.z, cx * uu.z)));
-    F3 dir = sel3(pick_light, dir_light, dir_cos);
-    const float dlen2 = dot3(dir, dir);
-    const float inv_len = fast_rsq(dlen2);
-    // pdf.rs:19-26
-    const float cos_w = dot3(dir, ww) * inv_len;
-    float pdf_val = cos_w > 0.0f ? cos_w * RT_INV_PI_F : 0.0f;
-    if (S.n_lights > 0) {
-      // XZRect::pdf_value, hitable.rs:245-254 (its hit test uses 0.001 and f64::MAX)
-      if (STATS) cnt.light_tests += scatters;
-      const float t = (S.light.f[4] - sf.p.y) * fast_rcp(dir.y);
-      const float lx = fmaf(t, dir.x, sf.p.x), lz = fmaf(t, dir.z, sf.p.z);
-      const bool miss = (t < 0.001f) | (t > 3.402823466e+38f) | (lx < S.light.f[0]) | (lx > S.light.f[1]) | (lz < S.light.f[2]) | (lz > S.light.f[3]);
-      const float area = (S.light.f[1] - S.light.f[0]) * (S.light.f[3] - S.light.f[2]);
-      const float cosine = fabsf(dir.y * inv_len);
-      const float lp = miss ? 0.0f : (t * t * dlen2) * fast_rcp(cosine * area);
-      pdf_val = 0.5f * lp + 0.5f * pdf_val;
-    }
-    // material.rs:76-82
-    const float cos_n = fmaxf(dot3(sf.normal, dir) * inv_len, 0.0f);
-    const float f = (cos_n * RT_INV_PI_F) * fast_rcp(pdf_val);
-    F3 thr_next = f3(thr.x * color.x * f, thr.y * color.y * f, thr.z * color.z * f);
-    bool scattered = scatters;
-    if (GENERAL && (S.mat_mask & ((1 << RT_MAT_METAL) | (1 << RT_MAT_DIELECTRIC) | (1 << RT_MAT_ISOTROPIC)))) {
-      // Materials of the reference's older scatter() -> (attenuation, ray) form
-      // (material.rs:100-112, 125-159, 217-221, commented out there): the path goes on
-      // along the returned ray weighted by the attenuation, with no pdf involved.
-      const bool deep = depth < a_max_depth;
-      const bool is_metal = hit & deep & (mat_type == RT_MAT_METAL);
-      const bool is_diel = hit & deep & (mat_type == RT_MAT_DIELECTRIC);
-      const bool is_iso = hit & deep & (mat_type == RT_MAT_ISOTROPIC);
-      if (__ballot(is_metal | is_diel | is_iso) != 0ull) {
-        // random_in_unit_sphere (main.rs:211-221): attempt a draws counter (pixel, sample, depth, 256+a)
-        F3 rs = f3(0, 0, 0);
-        bool looking = is_metal | is_iso;
-        unsigned attempt = 0;
-        while (__ballot(looking) != 0ull) {
-          const U4 sw = philox4x32_10(pixel_id, sample, (unsigned)depth, 256u + attempt, key0, key1);
-          const F3 c = f3(2.0f * u01(sw.x) - 1.0f, 2.0f * u01(sw.y) - 1.0f, 2.0f * u01(sw.z) - 1.0f);
-          const bool ok = looking & (dot3(c, c) < 1.0f);
-          rs = sel3(ok, c, rs);
-          looking &= !ok;
-          ++attempt;
-        }
-        const F3 n = sf.normal;
-        // Metal::scatter
-        const F3 refl_unit = reflect3(unit3(ray.d), n);
-        const F3 m_dir = f3(refl_unit.x + q.fuzz * rs.x, refl_unit.y + q.fuzz * rs.y, refl_unit.z + q.fuzz * rs.z);
-        const bool m_ok = dot3(m_dir, n) > 0.0f;
-        // Dielectric::scatter (reflects the un-normalised incoming direction, material.rs:126)
-        const F3 reflected = reflect3(ray.d, n);
-        const float dn = dot3(ray.d, n);
-        const float d_len = fast_sqrt(dot3(ray.d, ray.d));
-        const bool outside = !(dn > 0.0f);
-        const F3 on_ = outside ? n : f3(-n.x, -n.y, -n.z);
-        const float ni_over_nt = outside ? fast_rcp(q.ref_idx) : q.ref_idx;
-        const float cosine = outside ? -dn * fast_rcp(d_len) : q.ref_idx * dn * fast_rcp(d_len);
-        const F3 uvd = unit3(ray.d);
-        const float dt = dot3(uvd, on_);
-        const float disc = 1.0f - ni_over_nt * ni_over_nt * (1.0f - dt * dt);
-        const float sq = fast_sqrt(disc);
-        const F3 refracted = f3(ni_over_nt * (uvd.x - on_.x * dt) - on_.x * sq, ni_over_nt * (uvd.y - on_.y * dt) - on_.y * sq,
-                                ni_over_nt * (uvd.z - on_.z * dt) - on_.z * sq);
-        float r0 = (1.0f - q.ref_idx) * fast_rcp(1.0f + q.ref_idx);
-        r0 = r0 * r0;
-        const float om = 1.0f - cosine;
-        const float reflect_prob = disc > 0.0f ? r0 + (1.0f - r0) * (om * om) * (om * om) * om : 1.0f;
-        const float xi = u01(w.y << 1);
-        const F3 d_dir = xi < reflect_prob ? reflected : refracted;
-        // Isotropic::scatter
-        const F3 s_dir = is_metal ? m_dir : (is_diel ? d_dir : rs);
-        const F3 atten = is_diel ? f3(1.0f, 1.0f, 1.0f) : color;
-        const bool s_any = is_metal | is_diel | is_iso;
-        const bool s_ok = (is_metal & m_ok) | is_diel | is_iso;
-        dir = sel3(s_any, s_dir, dir);
-        thr_next = sel3(s_any, f3(thr.x * atten.x, thr.y * atten.y, thr.z * atten.z), thr_next);
-        scattered = s_any ? s_ok : scattered;
-      }
-    }
+    // ---- color(), main.rs:165-209, one vertex ----
+    const Shaded sh = shade_vertex<STATS, GENERAL>(S, dprim_tab, alive, h, ray, thr, depth, w, a_max_depth, a_sky, pixel_id, sample, key0, key1, cnt);
+    const F3 radiance = sh.radiance, dir = sh.dir, thr_next = sh.thr_next;
+    const bool scattered = sh.scattered, textured = sh.textured, emits = sh.emits;
     // A zero or NaN weight fixes the sample's value (0 after de_nan) whatever the
     // rest of the path does, so the path ends there.
     const bool go_on = scattered & ((thr_next.x > 0.0f) | (thr_next.y > 0.0f) | (thr_next.z > 0.0f));
@@ -1350,11 +1487,11 @@ __global__ void __launch_bounds__(64, (TRAV == TRAV_STACK && GENERAL != 2) ? 6 :
     }
     // A lane whose path ended gets a new origin and weight with its next path, so only
     // the direction is kept clean (it feeds the reciprocals' range test meanwhile).
-    ro = sf.p;
+    ro = sh.p;
     rd = sel3(go_on, dir, rd);
     if (GENERAL == 2) {
       const bool lit = textured & emits;  // its sample is thr * colour: the weight is kept for the top of the next trip
-      pend = (textured & (go_on | emits)) ? ((q.flags >> DP_INDEX_SHIFT) << 1) | (lit ? 1 : 0) : -1;
+      pend = (textured & (go_on | emits)) ? (sh.mat_index << 1) | (lit ? 1 : 0) : -1;
       thr = sel3(lit, thr, thr_next);
     } else {
       thr = thr_next;
@@ -1388,6 +1525,366 @@ __global__ void __launch_bounds__(64, (TRAV == TRAV_STACK && GENERAL != 2) ? 6 :
       for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off, 64);
       if (lane == 0) atomicAdd(&stats[k], x);
     }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// render_stack_kernel: the sample loop for scenes whose tree needs the per-lane
+// stack traversal.  Same work items, same pool of (pixel, sample) paths per wave,
+// same accumulators as render_kernel; what differs is that a lane's traversal
+// state (node, stack, best hit, ray in the current frame) lives across the shading
+// code.  The wave alternates between two phases:
+//   shading   - the lanes that are NOT in a traversal: finish the hit (media), shade
+//               the vertex, end or continue the path, take a new path from the pool,
+//               make the camera ray, start the next traversal;
+//   traversal - every lane with a ray steps through its tree until enough lanes
+//               have finished (RT_READY_LANES of them, or half of the live ones) to
+//               make a shading phase worth running.
+// So a lane whose ray ended early gets its next ray while its neighbours are still
+// inside their trees, instead of idling until the slowest ray of the wave is done.
+// ---------------------------------------------------------------------------
+#ifndef RT_READY_LANES
+#define RT_READY_LANES 48
+#endif
+#ifndef RT_SLOTS
+#define RT_SLOTS 2
+#endif
+// Diagnostic build (-DRT_PHASE_TIMING): shader-clock stamps around the parts of the loop, summed per wave into
+// stats[16..31] by the counting build and printed by rt_render.  No stamp exists in the normal build.
+#ifdef RT_PHASE_TIMING
+#define RT_STAMP(k) do { if (STATS) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); ph[k] += now_ - t_last; t_last = now_; } } while (0)
+#define RT_COUNT(k, v) do { if (STATS) ph[k] += (v); } while (0)
+#else
+#define RT_STAMP(k) do { } while (0)
+#define RT_COUNT(k, v) do { } while (0)
+#endif
+template <bool STATS, bool SUMSQ, int GENERAL>
+__global__ void __launch_bounds__(64, GENERAL != 2 ? 6 : 5) render_stack_kernel(DevScene S, DevCamera cam, RenderArgs A, float* __restrict__ out_sum,
+                                                     float* __restrict__ out_sumsq, unsigned long long* __restrict__ stats, unsigned* __restrict__ queue) {
+  // Up to RT_SLOTS work items are open per wave: the one lanes take new paths from (slot f) and earlier ones whose
+  // pools are empty and whose last paths are still on their way.  Paths reach depth 50 in scenes with media, and a
+  // wave that waited for its item's last path before opening the next one would run at a few lanes for most of its
+  // life.  A lane carries its item's slot with its pixel (slot * 64 + pixel in the tile) and adds its samples to
+  // that slot's accumulators; a slot's tile is written when its last path has ended.
+  __shared__ float acc[SUMSQ ? 6 : 3][RT_SLOTS * 64];
+  __shared__ int slot_info[RT_SLOTS][4];  // tile x, tile y, chunk
+  extern __shared__ float4 prim_lds[];  // the LDS part of the traversal stack: stack_lds entries of 64 lanes
+  LaneStack stk;
+  stk.lds = (unsigned*)prim_lds + (threadIdx.x & 63);
+  stk.n_lds = S.stack_lds;
+  const int lane = threadIdx.x & 63;
+  __shared__ float cam_lds[20];
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      cam_lds[k] = cam.origin[k];
+      cam_lds[3 + k] = cam.llc[k];
+      cam_lds[6 + k] = cam.horizontal[k];
+      cam_lds[9 + k] = cam.vertical[k];
+      cam_lds[12 + k] = cam.u[k];
+      cam_lds[15 + k] = cam.v[k];
+    }
+    cam_lds[18] = cam.lens_radius;
+  }
+  const bool has_lens = cam.lens_radius != 0.0f;
+  const float4* dprim_tab = (const float4*)S.dprims;
+  Counters cnt;
+  memset(&cnt, 0, sizeof(cnt));
+  const int n_tiles = A.n_tiles;
+  const int n_items = n_tiles * A.n_chunks;
+  float a_t_min = A.t_min;
+  int a_max_depth = A.max_depth, a_sky = A.sky;
+  int a_ready = A.ready_lanes, a_hold = A.hold_lanes;
+  asm volatile("" : "+s"(a_t_min), "+s"(a_max_depth), "+s"(a_sky), "+s"(a_ready), "+s"(a_hold));
+#ifdef RT_PHASE_TIMING
+  unsigned long long ph[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long t_last = __builtin_amdgcn_s_memtime();
+#endif
+  // Wave-uniform state of the open items.
+  unsigned open_mask = 0;      // slots that hold an item
+  int f = 0;                   // slot that new paths come from
+  bool fill_open = false;      // slot f's pool is not empty yet
+  bool queue_empty = false;
+  int tx = 0, ty = 0;          // tile of the item in slot f
+  int s_first = 0, pool_size = 0, pool_next = 0;  // its first sample and its pool
+
+  // Per-lane path state.
+  bool alive = false;  // on a path
+  bool trav = false;   // in a traversal (implies alive)
+  F3 ro = f3(0, 0, 0), rd = f3(0, 0, 1);  // the ray of the current segment, world frame
+  F3 thr = f3(0, 0, 0);
+  int depth = 0, pix = 0;  // pix: slot * 64 + pixel within the tile
+  unsigned pixel_id = 0, sample = 0;
+  int pend = -1;
+  // Per-lane traversal state.
+  RayF wr = make_ray(ro, rd);  // the world ray with its reciprocals
+  Trav T;
+  T.r = wr;
+  T.sp = 0;
+  T.cur = TRAV_POP;
+  T.best.t = INFINITY;
+  T.best.prim = -1;
+
+  for (;;) {
+    // ======================= work items (wave-uniform) =======================
+    {
+      const bool busy = alive | (GENERAL == 2 && pend >= 0);
+      if (fill_open && pool_next >= pool_size) fill_open = false;  // slot f goes on as a draining slot
+      unsigned draining = open_mask & ~(fill_open ? (1u << f) : 0u);
+      while (draining != 0u) {
+        const int d = __builtin_ctz(draining);
+        draining &= draining - 1u;
+        if (__ballot(busy & ((pix >> 6) == d)) != 0ull) continue;
+        // the last path of this item has ended: write its tile (main.rs:112-114; sums, not means)
+        const int dtx = slot_info[d][0], dty = slot_info[d][1], chunk = slot_info[d][2];
+        const size_t slab = (size_t)chunk * A.nx * A.ny * 3;
+        const int px = dtx * 8 + (lane & 7);
+        const int row = dty * 8 + (lane >> 3);
+        if (px < A.nx && row < A.ny) {
+          const size_t at = slab + ((size_t)row * A.nx + px) * 3;
+          out_sum[at] = acc[0][d * 64 + lane];
+          out_sum[at + 1] = acc[1][d * 64 + lane];
+          out_sum[at + 2] = acc[2][d * 64 + lane];
+          if (SUMSQ) {
+            out_sumsq[at] = acc[3][d * 64 + lane];
+            out_sumsq[at + 1] = acc[4][d * 64 + lane];
+            out_sumsq[at + 2] = acc[5][d * 64 + lane];
+          }
+        }
+        open_mask &= ~(1u << d);
+      }
+      if (!fill_open && !queue_empty && open_mask != (1u << RT_SLOTS) - 1u) {
+        int item = 0;
+        if (lane == 0) item = (int)atomicAdd(queue, 1u);
+        item = __builtin_amdgcn_readfirstlane(item);
+        if (item >= n_items) {
+          queue_empty = true;
+        } else {
+          f = __builtin_ctz(~open_mask);
+          const int chunk = item / n_tiles;
+          const int tile = item - chunk * n_tiles;
+          tx = tile % A.tiles_x;
+          ty = tile / A.tiles_x;
+          bool mine = true;
+          if (A.shard_count > 1) {
+            const int blocks_x = (A.nx + 63) / 64;
+            const int block = A.shard_index + (tile >> 6) * A.shard_count;
+            tx = (block % blocks_x) * 8 + (tile & 7);
+            ty = (block / blocks_x) * 8 + ((tile >> 3) & 7);
+            mine = (tx < A.tiles_x) & (ty < A.tiles_y);
+          }
+#pragma unroll
+          for (int c = 0; c < (SUMSQ ? 6 : 3); ++c) acc[c][f * 64 + lane] = 0.0f;
+          if (lane == 0) {
+            slot_info[f][0] = tx;
+            slot_info[f][1] = ty;
+            slot_info[f][2] = chunk;
+          }
+          // the last chunk comes in halving parts (see render_kernel)
+          const int n_whole = A.n_chunks - A.split_parts;
+          int s_len = A.chunk_spp;
+          s_first = chunk * A.chunk_spp;
+          if (chunk >= n_whole) {
+            const int k = chunk - n_whole;
+            const int last = A.spp - n_whole * A.chunk_spp;
+            const int o0 = last - (last >> k);
+            const int o1 = k + 1 < A.split_parts ? last - (last >> (k + 1)) : last;
+            s_first = n_whole * A.chunk_spp + o0;
+            s_len = o1 - o0;
+          }
+          pool_size = mine ? 64 * s_len : 0;
+          pool_next = 0;
+          open_mask |= 1u << f;
+          fill_open = true;
+        }
+      }
+      if (open_mask == 0u && queue_empty) break;
+    }
+
+    // ======================= shading phase: the lanes that are not in a traversal =======================
+    const bool ready = !trav;
+    if (GENERAL == 2 && S.textured) {
+      // Texture::value of the vertex before (see render_kernel): evaluated where little else is live.
+      if (__ballot(ready & (pend >= 0)) != 0ull) {
+        if (ready & (pend >= 0)) {
+          const F3 c = texture_value(S.textures, S.perlins, S.materials[pend >> 1].texture, ro);
+          const F3 v = f3(thr.x * c.x, thr.y * c.y, thr.z * c.z);
+          if (pend & 1) {
+            const float cr = v.x != v.x ? 0.0f : v.x, cg = v.y != v.y ? 0.0f : v.y, cb = v.z != v.z ? 0.0f : v.z;  // de_nan
+            if (cr != 0.0f || cg != 0.0f || cb != 0.0f) {
+              atomicAdd(&acc[0][pix], cr);
+              atomicAdd(&acc[1][pix], cg);
+              atomicAdd(&acc[2][pix], cb);
+              if (SUMSQ) {
+                atomicAdd(&acc[3][pix], cr * cr);
+                atomicAdd(&acc[4][pix], cg * cg);
+                atomicAdd(&acc[5][pix], cb * cb);
+              }
+            }
+          } else {
+            thr = v;
+          }
+          pend = -1;
+        }
+      }
+    }
+    RT_STAMP(0);  // texture
+    unsigned key0 = A.key0, key1 = A.key1;
+    asm volatile("" : "+s"(key0), "+s"(key1));
+    const bool act = ready & alive;  // lanes whose traversal has ended: shade that vertex
+    RT_COUNT(8, 1); RT_COUNT(9, __popcll(__ballot(act)));
+    if (__ballot(act) != 0ull) {
+      // what is left of world.hit: the ConstantMedium nodes (they draw random numbers)
+      if (GENERAL != 0 && S.n_scan > 0) {
+        const PathRng rng = {pixel_id, sample, (unsigned)depth, key0, key1};
+        scan_range<STATS, true, true, 0>(S, 0, S.n_scan, act, wr, a_t_min, INFINITY, rng, T.best, cnt);
+      }
+      RT_STAMP(1);  // media
+      const U4 w = philox4x32_10(pixel_id, sample, (unsigned)depth, 0u, key0, key1);
+      const Shaded sh = shade_vertex<STATS, GENERAL>(S, dprim_tab, act, T.best, wr, thr, depth, w, a_max_depth, a_sky, pixel_id, sample, key0, key1, cnt);
+      RT_STAMP(2);  // philox + shade
+      const bool go_on = act & sh.scattered & ((sh.thr_next.x > 0.0f) | (sh.thr_next.y > 0.0f) | (sh.thr_next.z > 0.0f));
+      const bool done = act & !go_on;
+      if (done) {
+        // de_nan (main.rs:252-264) then col += (main.rs:108)
+        const float cr = sh.radiance.x != sh.radiance.x ? 0.0f : sh.radiance.x;
+        const float cg = sh.radiance.y != sh.radiance.y ? 0.0f : sh.radiance.y;
+        const float cb = sh.radiance.z != sh.radiance.z ? 0.0f : sh.radiance.z;
+        if (cr != 0.0f || cg != 0.0f || cb != 0.0f) {
+          atomicAdd(&acc[0][pix], cr);
+          atomicAdd(&acc[1][pix], cg);
+          atomicAdd(&acc[2][pix], cb);
+          if (SUMSQ) {
+            atomicAdd(&acc[3][pix], cr * cr);
+            atomicAdd(&acc[4][pix], cg * cg);
+            atomicAdd(&acc[5][pix], cb * cb);
+          }
+        }
+      }
+      ro = sel3(act, sh.p, ro);
+      rd = sel3(go_on, sh.dir, rd);
+      if (GENERAL == 2) {
+        const bool lit = sh.textured & sh.emits;
+        pend = act ? ((sh.textured & (go_on | sh.emits)) ? (sh.mat_index << 1) | (lit ? 1 : 0) : -1) : pend;
+        thr = sel3(act, sel3(lit, thr, sh.thr_next), thr);
+      } else {
+        thr = sel3(act, sh.thr_next, thr);
+      }
+      depth += go_on ? 1 : 0;
+      alive = act ? go_on : alive;
+    }
+    RT_STAMP(3);  // deposit + state update
+    // A path that ended on a textured light keeps its lane until the colour has been added (top of the next shading phase).
+    const bool free_lane = ready & !alive & !(GENERAL == 2 && pend >= 0);
+    // ---- hand (pixel, sample) items to the free lanes (main.rs:96-101) ----
+    bool fresh = false;
+    const unsigned long long need = __ballot(free_lane);
+    if (need != 0ull && fill_open && pool_next < pool_size) {
+      const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(need >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)need, 0));
+      const int k = pool_next + rank;
+      pool_next += __popcll(need);
+      const bool take = free_lane & (k < pool_size);
+      const int kk = take ? k : 0;
+      const int c_pix = kk & 63;
+      const int px = tx * 8 + (c_pix & 7);
+      const int row = ty * 8 + (c_pix >> 3);
+      const bool start = take & (px < A.nx) & (row < A.ny);
+      pix = start ? (f * 64 + c_pix) : pix;
+      pixel_id = start ? (unsigned)((A.ny - 1 - row) * A.nx + px) : pixel_id;
+      sample = start ? (unsigned)(A.sample_begin + s_first + (kk >> 6)) : sample;
+      depth = start ? 0 : depth;
+      thr = sel3(start, f3(1.0f, 1.0f, 1.0f), thr);
+      fresh = start;
+      alive |= start;
+      if (STATS) cnt.paths += start;
+    }
+    if (__ballot(alive) == 0ull) continue;  // nothing to trace: back to the items (a pool at the image's edge, a pending colour)
+    // ---- camera ray of the fresh lanes (main.rs:102-105, camera.rs:53-62); word 0 of the vertex's Philox call ----
+    if (__ballot(fresh) != 0ull) {
+      const U4 w = philox4x32_10(pixel_id, sample, 0u, 0u, key0, key1);
+      const int px = tx * 8 + (pix & 7);
+      const int j = A.ny - 1 - (ty * 8 + ((pix >> 3) & 7));
+      const float u = ((float)px + (float)(w.x >> 16) * (1.0f / 65536.0f)) * A.inv_nx;
+      const float v = ((float)j + (float)(w.x & 0xffffu) * (1.0f / 65536.0f)) * A.inv_ny;
+      int c0 = 0;
+      asm volatile("" : "+v"(c0));
+      const float* cl = cam_lds + c0;
+      float rdx = 0.0f, rdy = 0.0f;
+      F3 offset = f3(0.0f, 0.0f, 0.0f);
+      if (has_lens) {
+        const float lens_radius = cl[18];
+        unsigned attempt = 0;
+        bool looking = fresh;
+        while (__ballot(looking) != 0ull) {
+          const U4 lw = philox4x32_10(pixel_id, sample, 0u, 1u + attempt, key0, key1);
+          const float dx = 2.0f * u01(lw.x) - 1.0f, dy = 2.0f * u01(lw.y) - 1.0f;
+          const bool ok = looking & (fmaf(dy, dy, dx * dx) < 1.0f);
+          rdx = ok ? lens_radius * dx : rdx;
+          rdy = ok ? lens_radius * dy : rdy;
+          looking &= !ok;
+          ++attempt;
+        }
+        offset = f3(fmaf(cl[15], rdy, cl[12] * rdx), fmaf(cl[16], rdy, cl[13] * rdx), fmaf(cl[17], rdy, cl[14] * rdx));
+      }
+      const F3 org = f3(cl[0] + offset.x, cl[1] + offset.y, cl[2] + offset.z);
+      const F3 dir = f3(fmaf(v, cl[9], fmaf(u, cl[6], cl[3])) - cl[0] - offset.x,
+                        fmaf(v, cl[10], fmaf(u, cl[7], cl[4])) - cl[1] - offset.y,
+                        fmaf(v, cl[11], fmaf(u, cl[8], cl[5])) - cl[2] - offset.z);
+      ro = sel3(fresh, org, ro);
+      rd = sel3(fresh, dir, rd);
+    }
+    RT_STAMP(4);  // refill + camera
+    // ---- world.hit(r, 0.001, INFINITY), main.rs:166: the lanes with a new segment start at the root ----
+    {
+      const bool go = ready & alive;
+      const RayF nr = make_ray(ro, rd);
+      if (STATS) cnt.rays += go;
+      Counters c2;  // (the root test of lanes that do not start a ray is not an event)
+      memset(&c2, 0, sizeof(c2));
+      const int first = trav_enter<STATS>(S, S.root_ref, 0, nr, a_t_min, INFINITY, c2);
+      if (STATS) cnt.node_tests += go;
+      wr.o = sel3(go, nr.o, wr.o); wr.d = sel3(go, nr.d, wr.d); wr.inv = sel3(go, nr.inv, wr.inv);
+      T.r.o = sel3(go, nr.o, T.r.o); T.r.d = sel3(go, nr.d, T.r.d); T.r.inv = sel3(go, nr.inv, T.r.inv);
+      T.cur = go ? first : T.cur;
+      T.sp = go ? 0 : T.sp;
+      T.best.t = go ? INFINITY : T.best.t;
+      T.best.prim = go ? -1 : T.best.prim;
+      trav |= go;
+    }
+    RT_STAMP(5);  // traversal start
+    // ======================= traversal phase =======================
+    for (;;) {
+      RT_COUNT(10, 1); RT_COUNT(11, __popcll(__ballot(trav)));
+      // one step for every lane that has one to make; a lane holding a list or instance leaf waits for the leaf code below
+      if (trav & !trav_holds_leaf(T.cur)) trav = trav_step<STATS>(S, stk, T, wr, a_t_min, INFINITY, cnt);
+      RT_STAMP(6);  // step
+      const bool hold = trav & trav_holds_leaf(T.cur);
+      const unsigned long long m_trav = __ballot(trav), m_hold = __ballot(hold);
+      // the leaf code runs once for all lanes that hold a leaf, when enough of the traversing lanes do
+      if (m_hold != 0ull && __popcll(m_hold) * 64 >= a_hold * __popcll(m_trav)) {
+        RT_COUNT(12, 1); RT_COUNT(13, __popcll(m_hold));
+        if (hold) trav_leaf<STATS>(S, stk, T, wr, a_t_min, INFINITY, cnt);
+      }
+      RT_STAMP(7);  // leaf code
+      // back to the shading phase when enough of the live lanes have a finished ray (RT_READY_LANES in 64)
+      const int n_alive = __popcll(__ballot(alive));
+      const int n_ready = n_alive - __popcll(__ballot(trav));
+      if (n_ready * 64 >= a_ready * n_alive) break;
+    }
+  }
+
+  if (STATS) {
+    const unsigned v[9] = {cnt.paths, cnt.rays, cnt.hits, cnt.node_tests, cnt.rect_tests, cnt.sphere_tests, cnt.instance_ops, cnt.shade_events, cnt.light_tests};
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      unsigned long long x = v[k];
+      for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off, 64);
+      if (lane == 0) atomicAdd(&stats[k], x);
+    }
+#ifdef RT_PHASE_TIMING
+    if (lane == 0)
+      for (int k = 0; k < 16; ++k) atomicAdd(&stats[16 + k], ph[k]);
+#endif
   }
 }
 
@@ -1473,7 +1970,10 @@ struct rt_ctx {
   void* d_dprims;
   void* d_leaf_box;
   void* d_bnodes;
-  void* d_bnodes2;
+  void* d_bnodes4;
+  void* d_sub_root_ref;
+  void* d_box6_index;
+  void* d_box6_recs;
   void* d_prim_rank;
   void* d_objects;
   void* d_materials;
@@ -1506,7 +2006,7 @@ int hip_fail(hipError_t e, const char* what) {
   } while (0)
 
 void free_scene(rt_ctx* ctx) {
-  void** ptrs[] = {&ctx->d_scan, &ctx->d_prims, &ctx->d_dprims, &ctx->d_leaf_box, &ctx->d_bnodes, &ctx->d_bnodes2, &ctx->d_prim_rank, &ctx->d_objects, &ctx->d_materials, &ctx->d_textures, &ctx->d_perlins};
+  void** ptrs[] = {&ctx->d_scan, &ctx->d_prims, &ctx->d_dprims, &ctx->d_leaf_box, &ctx->d_bnodes, &ctx->d_bnodes4, &ctx->d_sub_root_ref, &ctx->d_box6_index, &ctx->d_box6_recs, &ctx->d_prim_rank, &ctx->d_objects, &ctx->d_materials, &ctx->d_textures, &ctx->d_perlins};
   for (size_t i = 0; i < sizeof(ptrs) / sizeof(ptrs[0]); ++i) {
     if (*ptrs[i]) (void)hipFree(*ptrs[i]);
     *ptrs[i] = nullptr;
@@ -1848,6 +2348,67 @@ int build_bnodes(const rt_scene* s, int idx, std::vector<BNode>* out, std::vecto
   return RT_OK;
 }
 
+// The four-wide view of the tree under the interior node `idx` (see BNode4): its entry holds the node's
+// grandchildren, or a child itself where that child is a leaf.  Returns the entry's index in `out`.  `need` receives
+// the stack entries a lane can have in use below this entry: while it is inside one descendant the others it entered
+// wait on the stack, and an object's sub-tree adds its marker.
+struct Wide4Builder {
+  const rt_scene* s;
+  const std::vector<float>* y_top;
+  std::vector<BNode4> out;
+  std::vector<int> sub_root_ref;  // per object
+  int ref_of_leaf(int child) const {
+    const rt_node& c = s->nodes[child];
+    return c.right == 1 ? (BN2_LEAF | BN2_PRIM | ~c.left) : (BN2_LEAF | child);
+  }
+  // the reference of node `idx` (interior: builds its entry) and the stack it needs
+  int ref_of(int idx, int* need) {
+    const rt_node& n = s->nodes[idx];
+    if (n.left >= 0) return build(idx, need);
+    *need = 0;
+    if (n.right == 0 && s->objects[~n.left].kind == RT_OBJ_BVH) {
+      int sub = 0;
+      const int r = ref_of(s->objects[~n.left].first, &sub);
+      sub_root_ref[(size_t)~n.left] = r;
+      *need = 1 + sub;  // the marker that switches the lane back to the outer frame
+    }
+    return ref_of_leaf(idx);
+  }
+  int build(int idx, int* need) {
+    const rt_node& n = s->nodes[idx];
+    int kids[4], n_kids = 0;
+    const int two[2] = {n.left, n.right};
+    for (int c = 0; c < 2; ++c) {
+      const rt_node& ch = s->nodes[two[c]];
+      if (ch.left >= 0) { kids[n_kids++] = ch.left; kids[n_kids++] = ch.right; }
+      else kids[n_kids++] = two[c];
+    }
+    const int at = (int)out.size();
+    out.push_back(BNode4());
+    BNode4 b;
+    int deepest = 0;
+    for (int c = 0; c < 4; ++c) {
+      if (c < n_kids) {
+        const rt_node& k = s->nodes[kids[c]];
+        b.lox[c] = k.bmin[0]; b.loy[c] = k.bmin[1]; b.loz[c] = k.bmin[2];
+        b.hix[c] = k.bmax[0]; b.hiy[c] = k.bmax[1]; b.hiz[c] = k.bmax[2];
+        b.top[c] = (*y_top)[(size_t)kids[c]];
+        int sub = 0;
+        b.ref[c] = ref_of(kids[c], &sub);
+        if (sub > deepest) deepest = sub;
+      } else {
+        b.lox[c] = b.loy[c] = b.loz[c] = INFINITY;
+        b.hix[c] = b.hiy[c] = b.hiz[c] = -INFINITY;
+        b.top[c] = -INFINITY;
+        b.ref[c] = BN4_EMPTY;
+      }
+    }
+    out[(size_t)at] = b;
+    *need = n_kids - 1 + deepest;
+    return at;
+  }
+};
+
 template <class T> int upload(void** dst, const T* src, size_t n) {
   *dst = nullptr;
   const size_t bytes = (n ? n : 1) * sizeof(T);
@@ -1944,6 +2505,11 @@ int launch_render(rt_ctx* ctx, const rt_camera* cam, const rt_render_params* p, 
       ++A.n_chunks;
     }
   }
+  // scenes with media or the older materials have the heavier shading phase: it is run for fuller waves
+  A.ready_lanes = ctx->general != 0 ? 56 : RT_READY_LANES;
+  if (const char* e = getenv("RT_READY_LANES")) A.ready_lanes = atoi(e);  // tuning
+  A.hold_lanes = 16;
+  if (const char* e = getenv("RT_HOLD_LANES")) A.hold_lanes = atoi(e);
   float* k_sum = d_sum;
   float* k_sumsq = d_sumsq;
   unsigned* d_queue = no_alloc ? (unsigned*)ctx->scratch_ptr : ctx->d_queue;
@@ -1975,14 +2541,20 @@ int launch_render(rt_ctx* ctx, const rt_camera* cam, const rt_render_params* p, 
   const dim3 block(64);
   typedef void (*RenderFn)(DevScene, DevCamera, RenderArgs, float*, float*, unsigned long long*, unsigned*);
 #define RT_TRIO(ST, SQ, TR) render_kernel<ST, SQ, TR, 0>, render_kernel<ST, SQ, TR, 1>, render_kernel<ST, SQ, TR, 2>
-#define RT_ROW(ST, SQ) RT_TRIO(ST, SQ, TRAV_SCAN), RT_TRIO(ST, SQ, TRAV_FLAT), RT_TRIO(ST, SQ, TRAV_STACK)
+#define RT_ROW(ST, SQ) RT_TRIO(ST, SQ, TRAV_SCAN), RT_TRIO(ST, SQ, TRAV_FLAT), nullptr, nullptr, nullptr  /* stack scenes: render_stack_kernel */
   static const RenderFn table[36] = {RT_ROW(false, false), RT_ROW(false, true), RT_ROW(true, false), RT_ROW(true, true)};
 #undef RT_ROW
 #undef RT_TRIO
   const int trav = ctx->dev.stack_mode ? TRAV_STACK : (ctx->dev.flat ? TRAV_FLAT : TRAV_SCAN);
-  const RenderFn fn = table[(stats ? 18 : 0) + (d_sumsq ? 9 : 0) + trav * 3 + ctx->general];
+#define RT_STK(ST, SQ) render_stack_kernel<ST, SQ, 0>, render_stack_kernel<ST, SQ, 1>, render_stack_kernel<ST, SQ, 2>
+  static const RenderFn stack_table[12] = {RT_STK(false, false), RT_STK(false, true), RT_STK(true, false), RT_STK(true, true)};
+#undef RT_STK
+  RenderFn fn = table[(stats ? 18 : 0) + (d_sumsq ? 9 : 0) + trav * 3 + ctx->general];
+  // scenes on the per-lane stack traversal: the kernel that keeps a lane's traversal going across the shading code
+  if (trav == TRAV_STACK) fn = stack_table[(stats ? 6 : 0) + (d_sumsq ? 3 : 0) + ctx->general];
   size_t lds_bytes = trav == TRAV_FLAT ? (size_t)ctx->dev.n_dprims * 6 * sizeof(float4) : 0;
-  if (trav == TRAV_STACK) lds_bytes = (size_t)ctx->dev.stack_depth * 64 * sizeof(unsigned);
+  if (trav == TRAV_STACK) lds_bytes = (size_t)ctx->dev.stack_lds * 64 * sizeof(unsigned);
+
   // One wave for every slot a CU has (8 per SIMD); where the kernel's registers allow fewer, the rest
   // start when the first waves are done, find no item left and leave.  Never more waves than items.
   long long waves = 32LL * (ctx->n_cus > 0 ? ctx->n_cus : 1);
@@ -2031,7 +2603,7 @@ int rt_create(int device_id, rt_ctx** out) {
   hipDeviceProp_t prop;
   e = hipGetDeviceProperties(&prop, device_id);
   ctx->n_cus = e == hipSuccess ? prop.multiProcessorCount : 0;
-  if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_stats, 9 * sizeof(unsigned long long));
+  if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_stats, 32 * sizeof(unsigned long long));
   if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_queue, sizeof(unsigned));
   if (e == hipSuccess) e = hipEventCreate(&ctx->ev0);
   if (e == hipSuccess) e = hipEventCreate(&ctx->ev1);
@@ -2083,7 +2655,39 @@ int rt_upload_scene(rt_ctx* ctx, const rt_scene* s) {
   // More than a treelet's worth of leaves: per-lane stack traversal over the
   // breadth-first nodes; the scan array then keeps only the ConstantMedium nodes.
   const int depth = tree_depth(s, 0);
-  const bool stack_mode = B.any_interior && depth <= STACK_DEPTH - 2;
+  const bool want_stack = B.any_interior && depth <= STACK_DEPTH - 2;
+  // the four-wide entries of the interior nodes, and the six-rect records of the list leaves
+  Wide4Builder W;
+  W.s = s;
+  W.y_top = &B.y_top;
+  W.sub_root_ref.assign((size_t)s->n_objects, 0);
+  int root_ref = 0, stack_need = 0;
+  std::vector<int> box6_index((size_t)s->n_prims, -1);
+  std::vector<float> box6_recs;
+  if (want_stack) {
+    root_ref = W.ref_of(0, &stack_need);
+    if (W.out.size() > (size_t)BN_INDEX_MASK) return rt::set_error(RT_ERR_UNSUPPORTED, "too many nodes");
+    auto note_box6 = [&](int first, int count) {
+      if (!box6_flag(s, first, count)) return;
+      box6_index[(size_t)first] = (int)(box6_recs.size() / 20);
+      float g[20];
+      std::memset(g, 0, sizeof(g));
+      for (int pair = 0; pair < 3; ++pair) {
+        const rt_prim& q0 = s->prims[first + 2 * pair];
+        const rt_prim& q1 = s->prims[first + 2 * pair + 1];
+        for (int c = 0; c < 4; ++c) g[6 * pair + c] = q0.f[c];
+        g[6 * pair + 4] = q0.f[4];
+        g[6 * pair + 5] = q1.f[4];
+      }
+      box6_recs.insert(box6_recs.end(), g, g + 20);
+    };
+    for (int i = 0; i < s->n_nodes; ++i)
+      if (s->nodes[i].left < 0 && s->nodes[i].right > 1) note_box6(~s->nodes[i].left, s->nodes[i].right);
+    for (int i = 0; i < s->n_objects; ++i)
+      if (s->objects[i].kind == RT_OBJ_LIST) note_box6(s->objects[i].first, s->objects[i].count);
+  }
+  // a tree whose walk could need more stack than a lane has (LDS part + private part) takes the scan
+  const bool stack_mode = want_stack && stack_need + 2 <= RT_STACK_LDS + RT_STACK_PRIVATE;
   std::vector<BNode> bnodes;
   std::vector<int> prim_rank((size_t)s->n_prims, 0);
   std::vector<ScanNode> media_scan;
@@ -2149,34 +2753,10 @@ int rt_upload_scene(rt_ctx* ctx, const rt_scene* s) {
   B.leaf_box.resize(dprims.size() * 8, 0.0f);
   if ((rc = upload(&ctx->d_leaf_box, B.leaf_box.data(), B.leaf_box.size())) != RT_OK) return rc;
   if ((rc = upload(&ctx->d_bnodes, bnodes.data(), bnodes.size())) != RT_OK) return rc;
-  // the child-box records of the interior nodes (same index space; leaf entries stay zero)
-  std::vector<BNode2> bnodes2;
-  if (stack_mode) {
-    bnodes2.assign((size_t)s->n_nodes, BNode2());
-    std::memset(bnodes2.data(), 0, bnodes2.size() * sizeof(BNode2));
-    // With lists or instances at some leaves the wave gathers its lanes at the leaf code; when every leaf is one
-    // primitive the test is cheap and runs inside the descent loop.
-    int inline_single = BN2_INLINE;
-    for (int i = 0; i < s->n_nodes; ++i)
-      if (s->nodes[i].left < 0 && s->nodes[i].right != 1) inline_single = 0;
-    for (int i = 0; i < s->n_nodes; ++i) {
-      const rt_node& n = s->nodes[i];
-      if (n.left < 0) continue;
-      const rt_node& l = s->nodes[n.left];
-      const rt_node& r = s->nodes[n.right];
-      BNode2& b = bnodes2[(size_t)i];
-      for (int c = 0; c < 3; ++c) { b.lmin[c] = l.bmin[c]; b.lmax[c] = l.bmax[c]; b.rmin[c] = r.bmin[c]; b.rmax[c] = r.bmax[c]; }
-      auto ref_of = [inline_single](int child, const rt_node& c) {
-        if (c.left >= 0) return child;
-        return c.right == 1 ? (BN2_LEAF | BN2_PRIM | inline_single | ~c.left) : (BN2_LEAF | child);
-      };
-      b.left = ref_of(n.left, l);
-      b.right = ref_of(n.right, r);
-      b.l_top = B.y_top[(size_t)n.left];
-      b.r_top = B.y_top[(size_t)n.right];
-    }
-  }
-  if ((rc = upload(&ctx->d_bnodes2, bnodes2.data(), bnodes2.size())) != RT_OK) return rc;
+  if ((rc = upload(&ctx->d_bnodes4, W.out.data(), W.out.size())) != RT_OK) return rc;
+  if ((rc = upload(&ctx->d_sub_root_ref, W.sub_root_ref.data(), W.sub_root_ref.size())) != RT_OK) return rc;
+  if ((rc = upload(&ctx->d_box6_index, box6_index.data(), box6_index.size())) != RT_OK) return rc;
+  if ((rc = upload(&ctx->d_box6_recs, box6_recs.data(), box6_recs.size())) != RT_OK) return rc;
   if ((rc = upload(&ctx->d_prim_rank, prim_rank.data(), prim_rank.size())) != RT_OK) return rc;
   if ((rc = upload(&ctx->d_objects, s->objects, (size_t)s->n_objects)) != RT_OK) return rc;
   if ((rc = upload(&ctx->d_materials, s->materials, (size_t)s->n_materials)) != RT_OK) return rc;
@@ -2191,11 +2771,16 @@ int rt_upload_scene(rt_ctx* ctx, const rt_scene* s) {
   // flat: leaves only, and few enough primitives for the render kernel's LDS tables
   d.flat = (!B.any_interior && !stack_mode && dprims.size() <= (size_t)kFlatMaxPrims) ? 1 : 0;
   d.bnodes = (const BNode*)ctx->d_bnodes;
-  d.bnodes2 = (const BNode2*)ctx->d_bnodes2;
+  d.bnodes4 = (const BNode4*)ctx->d_bnodes4;
+  d.root_ref = root_ref;
+  d.sub_root_ref = (const int*)ctx->d_sub_root_ref;
+  d.box6_index = (const int*)ctx->d_box6_index;
+  d.box6_recs = (const float4*)ctx->d_box6_recs;
   d.prim_rank = (const int*)ctx->d_prim_rank;
   d.objects = (const rt_object*)ctx->d_objects;
   d.stack_mode = stack_mode ? 1 : 0;
-  d.stack_depth = stack_mode ? depth + 2 : 0;
+  d.stack_depth = stack_mode ? stack_need + 2 : 0;  // what the deepest walk can have in use, and a margin
+  d.stack_lds = d.stack_depth < RT_STACK_LDS ? d.stack_depth : RT_STACK_LDS;
   d.mat_mask = mat_mask;
   d.textured = textured;
   d.has_spheres = 0;
@@ -2243,7 +2828,7 @@ int rt_render(rt_ctx* ctx, const rt_camera* cam, const rt_render_params* params,
   if ((rc = stage(ctx, 0, bytes, (void**)&d_sum)) != RT_OK) return rc;
   if (out_sumsq && (rc = stage(ctx, 1, bytes, (void**)&d_sumsq)) != RT_OK) return rc;
   hipError_t e = hipSuccess;
-  if (stats) e = hipMemset(ctx->d_stats, 0, 9 * sizeof(unsigned long long));
+  if (stats) e = hipMemset(ctx->d_stats, 0, 32 * sizeof(unsigned long long));
   if (e == hipSuccess) e = hipEventRecord(ctx->ev0, 0);
   rc = RT_OK;
   if (e == hipSuccess) rc = launch_render(ctx, cam, params, d_sum, d_sumsq, stats != nullptr, 0);
@@ -2252,8 +2837,18 @@ int rt_render(rt_ctx* ctx, const rt_camera* cam, const rt_render_params* params,
   if (e == hipSuccess && rc == RT_OK) e = hipMemcpy(out_sum, d_sum, bytes, hipMemcpyDeviceToHost);
   if (e == hipSuccess && rc == RT_OK && out_sumsq) e = hipMemcpy(out_sumsq, d_sumsq, bytes, hipMemcpyDeviceToHost);
   if (e == hipSuccess && rc == RT_OK && stats) {
-    unsigned long long v[9];
+    unsigned long long v[32];
     e = hipMemcpy(v, ctx->d_stats, sizeof(v), hipMemcpyDeviceToHost);
+#ifdef RT_PHASE_TIMING
+    if (e == hipSuccess && ctx->dev.stack_mode) {
+      static const char* names[8] = {"texture", "media", "philox+shade", "deposit+update", "refill+camera", "start traversal", "steps", "leaf code"};
+      double total = 0;
+      for (int k = 0; k < 8; ++k) total += (double)v[16 + k];
+      for (int k = 0; k < 8; ++k) std::fprintf(stderr, "  phase %-16s %6.2f %%\n", names[k], 100.0 * (double)v[16 + k] / total);
+      std::fprintf(stderr, "  shading phases %llu, lanes per phase %.1f; step trips %llu, lanes per trip %.1f; leaf rounds %llu, lanes per round %.1f\n",
+                   v[24], (double)v[25] / (double)(v[24] ? v[24] : 1), v[26], (double)v[27] / (double)(v[26] ? v[26] : 1), v[28], (double)v[29] / (double)(v[28] ? v[28] : 1));
+    }
+#endif
     if (e == hipSuccess) {
       std::memset(stats, 0, sizeof(*stats));
       stats->paths = v[0]; stats->rays = v[1]; stats->hits = v[2]; stats->node_tests = v[3]; stats->rect_tests = v[4];
@@ -2295,7 +2890,7 @@ int rt_trace_closest(rt_ctx* ctx, const float* o, const float* d, size_t n, floa
   if (e == hipSuccess) {
     size_t blocks = (n + 255) / 256;
     if (blocks > 4096) blocks = 4096;
-    if (ctx->dev.stack_mode) hipLaunchKernelGGL(trace_kernel<TRAV_STACK>, dim3((unsigned)blocks), dim3(256), (size_t)ctx->dev.stack_depth * 4 * 64 * sizeof(unsigned), 0, ctx->dev, d_o, d_d, n, t_min, t_max, d_id, d_t, d_n, d_p);
+    if (ctx->dev.stack_mode) hipLaunchKernelGGL(trace_kernel<TRAV_STACK>, dim3((unsigned)blocks), dim3(256), (size_t)ctx->dev.stack_lds * 4 * 64 * sizeof(unsigned), 0, ctx->dev, d_o, d_d, n, t_min, t_max, d_id, d_t, d_n, d_p);
     else if (ctx->dev.flat) hipLaunchKernelGGL(trace_kernel<TRAV_FLAT>, dim3((unsigned)blocks), dim3(256), 0, 0, ctx->dev, d_o, d_d, n, t_min, t_max, d_id, d_t, d_n, d_p);
     else hipLaunchKernelGGL(trace_kernel<TRAV_SCAN>, dim3((unsigned)blocks), dim3(256), 0, 0, ctx->dev, d_o, d_d, n, t_min, t_max, d_id, d_t, d_n, d_p);
     e = hipGetLastError();

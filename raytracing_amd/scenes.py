@@ -150,7 +150,7 @@ def cornell_smoke_scene(ratio, smoke=True, flip_light=True):
 SMOKE_LIGHT_SHAPE = (113.0, 443.0, 127.0, 432.0, 554.0)
 
 
-def final_scene(ratio, seed=0x5EED0002, boxes_per_side=20, cluster=1000):
+def final_scene(ratio, seed=0x5EED0002, boxes_per_side=20, cluster=1000, marble=True, media=True):
     """The closing scene of "Ray Tracing: The Next Week", which the reference's
     README lists as not reached (README.md:12-14): it has no code for it, so this
     builder is written from the book with the pieces the reference does have: a
@@ -177,11 +177,13 @@ def final_scene(ratio, seed=0x5EED0002, boxes_per_side=20, cluster=1000):
     items.append(Sphere.new(vec3(260.0, 150.0, 45.0), 50.0, Dielectric.new(1.5)))
     items.append(Sphere.new(vec3(0.0, 150.0, 145.0), 50.0, Metal.new(vec3(0.8, 0.8, 0.9), 10.0)))
     items.append(Sphere.new(vec3(360.0, 150.0, 145.0), 70.0, Dielectric.new(1.5)))
-    items.append(ConstantMedium.new(Sphere.new(vec3(360.0, 150.0, 145.0), 70.0, Dielectric.new(1.5)), 0.2,
-                                    Texture.new_constant(vec3(0.2, 0.4, 0.9))))
-    items.append(ConstantMedium.new(Sphere.new(vec3(0.0, 0.0, 0.0), 5000.0, Dielectric.new(1.5)), 0.0001,
-                                    Texture.new_constant(scalar(1.0))))
-    items.append(Sphere.new(vec3(220.0, 280.0, 300.0), 80.0, Lambertian.new(Texture.new_noise(0.1))))
+    if media:  # (the switches exist for timing experiments: what the media and the marble cost)
+        items.append(ConstantMedium.new(Sphere.new(vec3(360.0, 150.0, 145.0), 70.0, Dielectric.new(1.5)), 0.2,
+                                        Texture.new_constant(vec3(0.2, 0.4, 0.9))))
+        items.append(ConstantMedium.new(Sphere.new(vec3(0.0, 0.0, 0.0), 5000.0, Dielectric.new(1.5)), 0.0001,
+                                        Texture.new_constant(scalar(1.0))))
+    items.append(Sphere.new(vec3(220.0, 280.0, 300.0), 80.0,
+                            Lambertian.new(Texture.new_noise(0.1)) if marble else Lambertian.new_from_color(vec3(0.5, 0.5, 0.5))))
     white = Lambertian.new_from_color(vec3(0.73, 0.73, 0.73))
     spheres = [Sphere.new(vec3(165.0 * rng.random(), 165.0 * rng.random(), 165.0 * rng.random()), 10.0, white)
                for _ in range(cluster)]

@@ -1,0 +1,6 @@
+#!/bin/bash
+# A/B of library builds under variants/ on the hierarchical scenes (run through gpurun from the repository root).
+for f in variants/*.so; do
+  echo "$f"
+  RT_AMD_LIB=$PWD/$f VARIANTS=0 bash tools/stack_ab.sh | grep -v kernel || exit 1
+done

@@ -22,7 +22,7 @@ out=os.environ['OUT']
 c=collections.defaultdict(list)
 for p in glob.glob(out+'/p*/*/*_counter_collection.csv'):
     for row in csv.DictReader(open(p)):
-        if 'render_kernel<false' in row['Kernel_Name']:
+        if 'render_' in row['Kernel_Name'] and 'kernel<false' in row['Kernel_Name']:
             c[row['Counter_Name']].append(float(row['Counter_Value']))
 v={k:min(x) for k,x in c.items()}
 for k in sorted(v): print("  %-24s %.5g" % (k, v[k]))

@@ -21,13 +21,13 @@ for v in ("ref","lbvh"):
     dur=None
     for p in glob.glob(out+'/%s_trace/*/*_kernel_trace.csv'%v):
         for row in csv.DictReader(open(p)):
-            if 'render_kernel<false' in row['Kernel_Name']:
+            if 'render_' in row['Kernel_Name'] and 'kernel<false' in row['Kernel_Name']:
                 d=(int(row['End_Timestamp'])-int(row['Start_Timestamp']))/1e6
                 dur=d if dur is None else min(dur,d)
     c=collections.defaultdict(list)
     for p in glob.glob(out+'/%s_fetch/*/*_counter_collection.csv'%v)+glob.glob(out+'/%s_l2/*/*_counter_collection.csv'%v):
         for row in csv.DictReader(open(p)):
-            if 'render_kernel<false' in row['Kernel_Name']:
+            if 'render_' in row['Kernel_Name'] and 'kernel<false' in row['Kernel_Name']:
                 c[row['Counter_Name']].append(float(row['Counter_Value']))
     fetch=min(c['FETCH_SIZE'])*1024*2 if c['FETCH_SIZE'] else float('nan')
     print("%-5s kernel %.3f ms; HBM read %.1f MB per launch (FETCH_SIZE KiB x 1024 x 2) = %.1f GB/s; L2 hits %.3g, misses %.3g, L1->L2 read requests %.3g" % (
