@@ -693,23 +693,31 @@ __device__ __forceinline__ void leaf_list_lane(const DevScene& S, int first, int
   else prim_list_lane<STATS>(S, first, count, r, t_min, t_max, best, cnt);
 }
 
-// The lane's stack: the first S.stack_lds entries of a lane live in LDS (one column per lane, consecutive entries 64
-// dwords apart), deeper ones in the lane's private memory.  The LDS part decides how many waves fit on a CU, and the
-// depth a walk can reach in the worst case (every box of every level entered) is several times what walks reach in
-// practice, so LDS holds what is used and the rest exists for safety.
-#define RT_STACK_PRIVATE 64
+// The lane's stack: a column of LDS (consecutive entries 64 dwords apart), sized by the launch to what the deepest
+// walk of the scene can need.  RT_STACK_PRIVATE > 0 builds a variant that keeps only the first RT_STACK_LDS entries
+// in LDS and deeper ones in the lane's private memory; measured, the private array costs more (13 % on the Book-1
+// scene) than the LDS it frees gains, so the default is LDS only and a tree whose walk could need more than
+// RT_STACK_LDS entries takes the scan traversal instead.
+#ifndef RT_STACK_PRIVATE
+#define RT_STACK_PRIVATE 0
+#endif
 #ifndef RT_STACK_LDS
-#define RT_STACK_LDS 16
+#define RT_STACK_LDS 64
 #endif
 struct LaneStack {
   unsigned* lds;  // this lane's column
   int n_lds;      // entries in LDS
+#if RT_STACK_PRIVATE > 0
   unsigned deep[RT_STACK_PRIVATE];
   __device__ __forceinline__ void put(int at, unsigned v) {
     if (at < n_lds) lds[at * 64] = v;
     else deep[at - n_lds] = v;
   }
   __device__ __forceinline__ unsigned get(int at) const { return at < n_lds ? lds[at * 64] : deep[at - n_lds]; }
+#else
+  __device__ __forceinline__ void put(int at, unsigned v) { lds[at * 64] = v; }
+  __device__ __forceinline__ unsigned get(int at) const { return lds[at * 64]; }
+#endif
 };
 
 // The state of one lane's walk through the four-wide tree.
