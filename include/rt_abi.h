@@ -280,6 +280,41 @@ int rt_render_device(rt_ctx* ctx, const rt_camera* cam, const rt_render_params* 
 int rt_render_device_noalloc(rt_ctx* ctx, const rt_camera* cam, const rt_render_params* params,
                              float* d_sum_rgb, float* d_sumsq_rgb_or_null, void* hip_stream);
 
+/* ------------------------------------------------------------------------
+ * Several GPUs of one node from ONE process: what main.rs:70-133 does with its
+ * 8 threads (each renders its share, the shares are combined into one image),
+ * with GPUs for threads.  device_ids lists one device per rank; an id may
+ * repeat, which gives ranks that share a GPU (the way to check a split on a
+ * machine with one GPU).  The scene is replicated on every rank.
+ *   RT_SHARD_SAMPLES  rank g renders samples [g*spp/N, (g+1)*spp/N) of every pixel
+ *                     (main.rs:74-78) and the frames are summed onto rank 0
+ *                     (main.rs:128-133): nx*ny*12 bytes per rank.
+ *   RT_SHARD_TILES    rank g renders the 64x64-pixel blocks b with b % N == g at
+ *                     the full sample count; each rank sends only its own blocks
+ *                     and rank 0 puts them in place: nx*ny*12/N bytes per rank,
+ *                     no arithmetic.
+ * With distinct device ids the exchange is RCCL on the ranks' streams (one
+ * communicator per rank from ncclCommInitAll; ncclReduce, or grouped
+ * ncclSend/ncclRecv); librccl.so is opened when such a context is created.  With
+ * repeated ids, or RT_MULTI_NO_RCCL, rank 0's stream copies the other ranks'
+ * buffers over and adds or places them in rank order.  Results equal a
+ * one-rank render up to the order of fp32 additions (tile mode: up to how each
+ * launch splits a tile's samples into partial sums), because every (pixel,
+ * sample) has its own random-number counter.  Not thread-safe. */
+#define RT_SHARD_SAMPLES 0
+#define RT_SHARD_TILES 1
+#define RT_MULTI_NO_RCCL 1u
+typedef struct rt_multi rt_multi;
+int rt_multi_create(const int* device_ids, int n_devices, unsigned flags, rt_multi** out);
+int rt_multi_destroy(rt_multi* m);
+int rt_multi_uses_rccl(const rt_multi* m); /* 1 when the exchange goes through RCCL */
+int rt_multi_upload_scene(rt_multi* m, const rt_scene* scene);
+/* rt_render over the ranks.  params describes the whole image (shard_count 1);
+ * stats_per_rank (optional, n_devices entries) receives each rank's event counts
+ * and the device time of its render kernel.  Blocking. */
+int rt_multi_render(rt_multi* m, const rt_camera* cam, const rt_render_params* params, int shard_mode,
+                    float* out_sum_rgb, float* out_sumsq_rgb_or_null, rt_stats* stats_per_rank_or_null);
+
 /* Nearest-hit query on a batch of rays: the world.hit(r, t_min, t_max) of
  * src/main.rs:166 without any random numbers (media are skipped).  o and d are
  * n*3 floats.  prim_id[i] is the index into prims of the primitive hit, or -1;

@@ -8,5 +8,5 @@ Layout:
   render.py           Renderer: one rt_ctx per GPU
 """
 from ._lib import RtError, make_params  # noqa: F401
-from .render import Renderer, render_image  # noqa: F401
+from .render import MultiRenderer, Renderer, render_image  # noqa: F401
 from .scene import Scene  # noqa: F401

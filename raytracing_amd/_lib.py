@@ -24,6 +24,8 @@ RT_XFORM_ROTATE_Y, RT_XFORM_TRANSLATE = 1, 2
 RT_MAT_LAMBERTIAN, RT_MAT_DIFFUSE_LIGHT, RT_MAT_METAL, RT_MAT_DIELECTRIC, RT_MAT_ISOTROPIC = 0, 1, 2, 3, 4
 RT_TEX_CONSTANT, RT_TEX_CHECKER, RT_TEX_NOISE = 0, 1, 2
 RT_SKY_BLACK, RT_SKY_GRADIENT = 0, 1
+RT_SHARD_SAMPLES, RT_SHARD_TILES = 0, 1
+RT_MULTI_NO_RCCL = 1
 
 
 class rt_node(C.Structure):
@@ -132,6 +134,11 @@ def lib():
     sig("rt_render_device", C.c_int, vp, C.POINTER(rt_camera), C.POINTER(rt_render_params), vp, vp, vp)
     sig("rt_render_device_noalloc", C.c_int, vp, C.POINTER(rt_camera), C.POINTER(rt_render_params), vp, vp, vp)
     sig("rt_tonemap_device", C.c_int, vp, vp, C.c_int32, C.c_int32, C.c_int32, vp, vp)
+    sig("rt_multi_create", C.c_int, C.POINTER(C.c_int), C.c_int, C.c_uint, C.POINTER(vp))
+    sig("rt_multi_destroy", C.c_int, vp)
+    sig("rt_multi_uses_rccl", C.c_int, vp)
+    sig("rt_multi_upload_scene", C.c_int, vp, C.POINTER(rt_scene))
+    sig("rt_multi_render", C.c_int, vp, C.POINTER(rt_camera), C.POINTER(rt_render_params), C.c_int, vp, vp, vp)
     sig("rt_trace_closest", C.c_int, vp, vp, vp, C.c_size_t, C.c_float, C.c_float, vp, vp, vp, vp)
     sig("rt_tonemap", C.c_int, vp, vp, C.c_int32, C.c_int32, C.c_int32, vp)
     sig("rt_selftest_reciprocal", C.c_int, vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32))

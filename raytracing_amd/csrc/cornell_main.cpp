@@ -96,8 +96,12 @@ int main(int argc, char** argv) {
   const long quality = argc > 2 ? std::atol(argv[2]) : 100;  // main.rs:54-58
   const std::string path = argc > 3 ? argv[3] : "cornell_box.png";
   const unsigned long long seed = argc > 4 ? std::strtoull(argv[4], nullptr, 0) : 0x5EED0001ull;
-  if (factor <= 0 || quality <= 0) {
-    std::fprintf(stderr, "usage: cornell_main [factor [quality [out.png [seed]]]]\n");
+  // The reference spreads the samples over 8 threads (main.rs:70); here over `gpus` GPUs of the node (devices 0..gpus-1).
+  // A negative count gives that many ranks that all share GPU 0; "tiles" splits the image by 64x64 blocks instead of samples.
+  const long gpus = argc > 5 ? std::atol(argv[5]) : 1;
+  const bool by_tiles = argc > 6 && std::strcmp(argv[6], "tiles") == 0;
+  if (factor <= 0 || quality <= 0 || gpus == 0 || gpus > 64 || gpus < -64) {
+    std::fprintf(stderr, "usage: cornell_main [factor [quality [out.png [seed [gpus [samples|tiles]]]]]]\n");
     return 2;
   }
   const int nx = (int)(100 * factor), ny = (int)(100 * factor), ns = (int)quality;
@@ -121,16 +125,36 @@ int main(int argc, char** argv) {
   }
   const rt_scene scene = flat.view();
 
-  rt_ctx* ctx = nullptr;
-  if (rt_create(0, &ctx) != RT_OK) return fail("rt_create");
-  if (rt_upload_scene(ctx, &scene) != RT_OK) return fail("rt_upload_scene");
   rt_render_params params;
   std::memset(&params, 0, sizeof(params));
   params.nx = nx; params.ny = ny; params.spp = ns; params.max_depth = 50; params.sky = RT_SKY_BLACK; params.t_min = 0.001f;
   params.shard_count = 1; params.seed = seed;
   std::vector<float> sums((size_t)nx * ny * 3);
   rt_stats stats;
-  if (rt_render(ctx, &camera, &params, sums.data(), nullptr, &stats) != RT_OK) return fail("rt_render");
+  std::memset(&stats, 0, sizeof(stats));
+  rt_ctx* ctx = nullptr;
+  if (rt_create(0, &ctx) != RT_OK) return fail("rt_create");
+  if (gpus == 1) {
+    if (rt_upload_scene(ctx, &scene) != RT_OK) return fail("rt_upload_scene");
+    if (rt_render(ctx, &camera, &params, sums.data(), nullptr, &stats) != RT_OK) return fail("rt_render");
+  } else {
+    const int n = (int)(gpus < 0 ? -gpus : gpus);
+    std::vector<int> ids((size_t)n, 0);
+    if (gpus > 0)
+      for (int g = 0; g < n; ++g) ids[(size_t)g] = g;
+    rt_multi* multi = nullptr;
+    if (rt_multi_create(ids.data(), n, 0, &multi) != RT_OK) return fail("rt_multi_create");
+    if (rt_multi_upload_scene(multi, &scene) != RT_OK) return fail("rt_multi_upload_scene");
+    std::vector<rt_stats> per_rank((size_t)n);
+    if (rt_multi_render(multi, &camera, &params, by_tiles ? RT_SHARD_TILES : RT_SHARD_SAMPLES, sums.data(), nullptr, per_rank.data()) != RT_OK)
+      return fail("rt_multi_render");
+    for (const rt_stats& r : per_rank) {  // the job: counts add up, the time is the slowest rank's
+      stats.paths += r.paths;
+      stats.rays += r.rays;
+      if (r.kernel_ms > stats.kernel_ms) stats.kernel_ms = r.kernel_ms;
+    }
+    rt_multi_destroy(multi);
+  }
   std::vector<unsigned char> rgb((size_t)nx * ny * 3);
   if (rt_tonemap(ctx, sums.data(), nx, ny, ns, rgb.data()) != RT_OK) return fail("rt_tonemap");
   rt_destroy(ctx);

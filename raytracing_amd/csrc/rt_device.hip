@@ -2596,6 +2596,31 @@ int launch_render(rt_ctx* ctx, const rt_camera* cam, const rt_render_params* p, 
 
 int rt::context_device(const rt_ctx* ctx) { return ctx->device; }
 
+int rt::enqueue_render(rt_ctx* ctx, const rt_camera* cam, const rt_render_params* params, float* d_sum, float* d_sumsq, bool stats, void* stream) {
+  if (!ctx || !cam || !d_sum) return rt::set_error(RT_ERR_INVALID, "render: null argument");
+  if (!ctx->has_scene) return rt::set_error(RT_ERR_NO_SCENE, "render: no scene uploaded");
+  const int rc = check_params(params);
+  if (rc != RT_OK) return rc;
+  HIP_TRY(hipSetDevice(ctx->device));
+  return launch_render(ctx, cam, params, d_sum, d_sumsq, stats, (hipStream_t)stream);
+}
+
+int rt::reset_counters(rt_ctx* ctx) {
+  HIP_TRY(hipSetDevice(ctx->device));
+  HIP_TRY(hipMemset(ctx->d_stats, 0, 32 * sizeof(unsigned long long)));
+  return RT_OK;
+}
+
+int rt::read_counters(rt_ctx* ctx, rt_stats* out) {
+  HIP_TRY(hipSetDevice(ctx->device));
+  unsigned long long v[9];
+  HIP_TRY(hipMemcpy(v, ctx->d_stats, sizeof(v), hipMemcpyDeviceToHost));
+  std::memset(out, 0, sizeof(*out));
+  out->paths = v[0]; out->rays = v[1]; out->hits = v[2]; out->node_tests = v[3]; out->rect_tests = v[4];
+  out->sphere_tests = v[5]; out->instance_ops = v[6]; out->shade_events = v[7]; out->light_tests = v[8];
+  return RT_OK;
+}
+
 extern "C" {
 
 int rt_create(int device_id, rt_ctx** out) {

@@ -122,6 +122,53 @@ class Renderer(object):
         return int(count.value), [int(b) for b in bad]
 
 
+class MultiRenderer(object):
+    """One render over several GPUs from this process (rt_multi_*): the thread
+    fan-out and the image sum of main.rs:70-133 with GPUs for threads.  A device id
+    may repeat (ranks that share a GPU)."""
+
+    def __init__(self, device_ids, no_rccl=False):
+        ids = (C.c_int * len(device_ids))(*device_ids)
+        self._m = C.c_void_p()
+        self.n = len(device_ids)
+        check(_lib.lib().rt_multi_create(ids, len(device_ids), _lib.RT_MULTI_NO_RCCL if no_rccl else 0, C.byref(self._m)))
+
+    @property
+    def uses_rccl(self):
+        return bool(_lib.lib().rt_multi_uses_rccl(self._m))
+
+    def close(self):
+        if self._m:
+            _lib.lib().rt_multi_destroy(self._m)
+            self._m = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def upload_scene(self, flat_scene):
+        check(_lib.lib().rt_multi_upload_scene(self._m, C.byref(flat_scene)))
+
+    def render(self, camera, params, mode="samples", want_sumsq=False, want_stats=False):
+        """Sums (ny, nx, 3), top row first; optionally sums of squares and the
+        per-rank event counters."""
+        shape = (params.ny, params.nx, 3)
+        s = np.zeros(shape, dtype=np.float32)
+        s2 = np.zeros(shape, dtype=np.float32) if want_sumsq else None
+        stats = (_lib.rt_stats * self.n)() if want_stats else None
+        shard = {"samples": _lib.RT_SHARD_SAMPLES, "tiles": _lib.RT_SHARD_TILES}[mode]
+        check(_lib.lib().rt_multi_render(self._m, C.byref(camera.c), C.byref(params), shard, s.ctypes.data,
+                                         s2.ctypes.data if want_sumsq else None, stats))
+        out = [s]
+        if want_sumsq:
+            out.append(s2)
+        if want_stats:
+            out.append(list(stats))
+        return tuple(out) if len(out) > 1 else s
+
+
 def render_image(scene, camera, world, nx, ny, ns, seed=0x5EED0001, light_shape=None, device_id=0, png_path=None):
     """main(): flatten `world`, render ns samples per pixel, return the 8-bit
     image (main.rs:65-155) and, with `png_path`, write it as the reference does

@@ -1,0 +1,117 @@
+"""rt_multi_*: one render over several ranks from one process (the thread fan-out
+and image sum of main.rs:70-133 with GPUs for threads).  The GPU box has one GPU,
+so ranks share it ("virtual ranks": repeated device ids, exchange by device
+copies in rank order); the RCCL exchange is driven with the one real device,
+where ncclReduce and the grouped send/recv degenerate to a single rank but the
+communicator set-up and the calls are the ones N devices take."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from raytracing_amd import MultiRenderer, RtError, Scene, make_params, scenes
+from raytracing_amd._lib import RT_ERR_INVALID
+
+pytestmark = pytest.mark.gpu
+
+
+def test_one_rank_through_rccl_equals_rt_render(gpu, cornell):
+    gpu.upload_scene(cornell.flat)
+    p = make_params(96, 80, 40, seed=3)
+    want, want2 = gpu.render(cornell.camera, p, want_sumsq=True)
+    m = MultiRenderer([0])
+    try:
+        assert m.uses_rccl
+        m.upload_scene(cornell.flat)
+        for mode in ("samples", "tiles"):
+            got, got2, stats = m.render(cornell.camera, p, mode=mode, want_sumsq=True, want_stats=True)
+            assert np.array_equal(got, want) and np.array_equal(got2, want2)
+            assert stats[0].paths == 96 * 80 * 40 and stats[0].kernel_ms > 0
+    finally:
+        m.close()
+
+
+@pytest.mark.parametrize("n_ranks", [2, 3, 8])
+def test_virtual_ranks_reproduce_the_one_rank_image(gpu, cornell, n_ranks):
+    """N ranks on one device: by samples the frames add up to the one-rank image up
+    to fp32 summation order; by tiles the gathered image equals, bit for bit, the
+    tile shards rendered one by one through rt_render and added."""
+    gpu.upload_scene(cornell.flat)
+    nx, ny, spp = 200, 136, 48  # 4 x 3 blocks of 64x64, the last column and row ragged
+    p = make_params(nx, ny, spp, seed=17)
+    whole, whole2 = gpu.render(cornell.camera, p, want_sumsq=True)
+    m = MultiRenderer([0] * n_ranks)
+    try:
+        assert not m.uses_rccl
+        m.upload_scene(cornell.flat)
+        s, s2, stats = m.render(cornell.camera, p, mode="samples", want_sumsq=True, want_stats=True)
+        assert sum(st.paths for st in stats) == nx * ny * spp
+        assert np.allclose(s, whole, rtol=2e-6, atol=1e-5) and np.allclose(s2, whole2, rtol=2e-6, atol=1e-4)
+        t, t2 = m.render(cornell.camera, p, mode="tiles", want_sumsq=True)
+        parts = np.zeros_like(whole)
+        for k in range(n_ranks):
+            parts += gpu.render(cornell.camera, make_params(nx, ny, spp, seed=17, shard_index=k, shard_count=n_ranks))
+        assert np.array_equal(t, parts)
+        assert np.allclose(t, whole, rtol=2e-6, atol=1e-5) and np.allclose(t2, whole2, rtol=2e-6, atol=1e-4)
+    finally:
+        m.close()
+
+
+def test_more_ranks_than_blocks_and_a_tree_scene(gpu, orc):
+    """100x60 pixels are two 64x64 blocks: with five ranks three have nothing to
+    render.  The scene is a sphere field on the stack traversal, whose per-pixel
+    sums depend on scheduling in their last bits, hence the tolerance."""
+    from test_gpu_materials import _sphere_field
+    with Scene(61) as sc:
+        cam, world = _sphere_field(120, 5, glass_and_metal=False)
+        flat = sc.flatten(world)
+    gpu.upload_scene(flat)
+    p = make_params(100, 60, 32, seed=8)
+    whole = gpu.render(cam, p)
+    m = MultiRenderer([0] * 5)
+    try:
+        m.upload_scene(flat)
+        for mode in ("tiles", "samples"):
+            s = m.render(cam, p, mode=mode)
+            assert np.allclose(s, whole, rtol=1e-5, atol=1e-4), mode
+            assert s.sum() > 0
+    finally:
+        m.close()
+
+
+def test_multi_argument_errors(gpu, cornell):
+    with pytest.raises(RtError):
+        MultiRenderer([0, 99])
+    m = MultiRenderer([0, 0], no_rccl=True)
+    try:
+        with pytest.raises(RtError) as e:
+            m.render(cornell.camera, make_params(8, 8, 4))
+        assert "no scene" in str(e.value)
+        m.upload_scene(cornell.flat)
+        with pytest.raises(RtError) as e:
+            m.render(cornell.camera, make_params(8, 8, 1), mode="samples")  # fewer samples than ranks
+        assert e.value.code == RT_ERR_INVALID
+        with pytest.raises(RtError):
+            m.render(cornell.camera, make_params(8, 8, 4, shard_index=1, shard_count=2))
+        assert m.render(cornell.camera, make_params(8, 8, 1), mode="tiles").sum() >= 0
+    finally:
+        m.close()
+
+
+def test_cpp_host_program_over_three_ranks(gpu, tmp_path):
+    """cornell_main with its samples spread over three ranks of GPU 0 (the
+    reference spreads them over 8 threads) writes the one-rank image up to the
+    last bit of a few pixels' sums."""
+    from conftest import ROOT
+    from raytracing_amd.png import read_png
+    exe = os.path.join(ROOT, "raytracing_amd", "csrc", "cornell_main")
+    one, three, tiles = (str(tmp_path / n) for n in ("one.png", "three.png", "tiles.png"))
+    for out, extra in ((one, []), (three, ["-3"]), (tiles, ["-3", "tiles"])):
+        run = subprocess.run([exe, "2", "24", out, "777"] + extra, capture_output=True, text=True, timeout=120)
+        assert run.returncode == 0, run.stderr
+        assert "200x200, 24 samples per pixel, 960000 paths" in run.stdout
+    a = read_png(one).astype(np.int32)
+    for other in (three, tiles):
+        b = read_png(other).astype(np.int32)
+        assert np.abs(a - b).max() <= 1 and (a != b).mean() < 1e-3
