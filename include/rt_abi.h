@@ -140,9 +140,20 @@ typedef struct rt_perlin {
 
 /* Light shapes for HitablePDF (src/pdf.rs:33-50).  Only XZRect overrides
  * pdf_value/random in the reference (src/hitable.rs:245-264); color() builds
- * XZRect(213,343,227,332,554) inline (src/main.rs:177-178).
- * f = {x0, x1, z0, z1, k, 0}.  Zero lights means CosinePDF alone. */
+ * XZRect(213,343,227,332,554) inline (src/main.rs:177-178): one RT_LIGHT_XZ_RECT,
+ * f = {x0, x1, z0, z1, k, 0}, reproduces that.  Zero lights means CosinePDF alone.
+ * Beyond the reference (it has no code for them): XY and YZ rects with the same
+ * formulas on their own axes (f = constructor order a0,a1,b0,b1,k); spheres
+ * (f = {cx,cy,cz,r}) with the pdf_value/random of "Ray Tracing: The Rest of Your
+ * Life" (uniform over the cone the sphere subtends); and up to RT_MAX_LIGHTS
+ * shapes at once, as a HitableList whose random() picks one shape uniformly and
+ * whose pdf_value() is the mean of the shapes'.  The MixturePDF stays 50/50
+ * between that HitablePDF and the CosinePDF (src/pdf.rs:52-76). */
 #define RT_LIGHT_XZ_RECT 0
+#define RT_LIGHT_XY_RECT 1
+#define RT_LIGHT_YZ_RECT 2
+#define RT_LIGHT_SPHERE 3
+#define RT_MAX_LIGHTS 64
 
 typedef struct rt_light {
   int32_t type;
@@ -164,7 +175,7 @@ typedef struct rt_scene {
   const rt_perlin* perlins;
   int32_t n_perlins;
   const rt_light* lights;
-  int32_t n_lights; /* 0 or 1 */
+  int32_t n_lights; /* 0 .. RT_MAX_LIGHTS */
 } rt_scene;
 
 /* Camera (src/camera.rs:5-14) in f64 exactly as Camera::new computes it;
@@ -215,6 +226,8 @@ typedef struct rt_render_params {
  * sub 1+a at depth 0, words 0,1: attempt a of random_in_unit_disk (src/camera.rs:65-75).
  * sub 256+a, words 0..2: attempt a of random_in_unit_sphere (src/main.rs:211-221).
  * sub 4096+m, word 0: the ConstantMedium draw of medium m (src/hitable.rs:582).
+ * sub 8192, word 0 (only with more than one light shape): the shape HitablePDF
+ *           generates from is number (word * n_lights) >> 32.
  * A 32-bit word x becomes a uniform in [0,1) as (x >> 8) * 2^-24. */
 
 typedef struct rt_stats {

@@ -59,6 +59,15 @@ int rtb_light_xz_rect(rt_builder* b, double x0, double x1, double z0, double z1,
  * Returns how many such items the list holds (0: nothing changed).  For the Cornell box this registers exactly
  * the numbers src/main.rs:178 hard-codes, which are those of src/scenes.rs:310-317. */
 int rtb_light_from_world(rt_builder* b, int world_list);
+/* Beyond the reference (whose color() samples one XZRect): APPENDS a shape to the list HitablePDF samples.
+ * type is RT_LIGHT_*; rects take a0,a1,b0,b1,k in their constructor's order, a sphere cx,cy,cz,r (e unused).
+ * Returns the number of shapes now registered. */
+int rtb_light_add(rt_builder* b, int type, double a, double bb, double c, double d, double e);
+/* Registers EVERY item of `world_list` that can be sampled and carries a DiffuseLight material: XY, XZ and YZ
+ * rects (bare or under FlipNormals) and spheres, in list order, replacing any set before (at most RT_MAX_LIGHTS;
+ * further ones are left out).  Returns how many were registered.  random_scene's emissive spheres
+ * (src/scenes.rs:87-92 and the small ones) become light shapes this way. */
+int rtb_lights_from_world(rt_builder* b, int world_list);
 
 /* Builds the world BvhNode over the items of `world_list` (src/main.rs:85-90)
  * and flattens.  *out points into memory owned by the builder, valid until the

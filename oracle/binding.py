@@ -105,6 +105,30 @@ def render(scene, camera, params, mode=ORC_F64, n_threads=8, split_samples=False
     return tuple(out) if len(out) > 1 else out[0]
 
 
+def light_pdf_value(light, o, dirs):
+    """Hitable::pdf_value(o, dir) of one rt_light for an (n, 3) array of directions (f64)."""
+    dirs = np.ascontiguousarray(dirs, dtype=np.float64)
+    oo = (C.c_double * 3)(*[float(x) for x in o])
+    out = np.zeros(dirs.shape[0], dtype=np.float64)
+    f = lib().orc_light_pdf_value
+    f.restype = None
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    f(C.addressof(light), oo, dirs.ctypes.data, dirs.shape[0], out.ctypes.data)
+    return out
+
+
+def light_random(light, o, xi):
+    """Hitable::random(o) of one rt_light for an (n, 2) array of uniforms (f64): (n, 3) directions."""
+    xi = np.ascontiguousarray(xi, dtype=np.float64)
+    oo = (C.c_double * 3)(*[float(x) for x in o])
+    out = np.zeros((xi.shape[0], 3), dtype=np.float64)
+    f = lib().orc_light_random
+    f.restype = None
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    f(C.addressof(light), oo, xi.ctypes.data, xi.shape[0], out.ctypes.data)
+    return out
+
+
 def tonemap(sum_rgb, spp_total):
     a = np.ascontiguousarray(sum_rgb, dtype=np.float64)
     ny, nx = a.shape[0], a.shape[1]

@@ -223,16 +223,11 @@ template <class P> struct World {
     v = (theta + PI / R(2)) / PI;
   }
 
-  // ---- hitable.rs:49-84 Sphere::hit ----
-  bool sphere_hit(int idx, const Ray<P>& r, R t_min, R t_max, HitRecord<R>& rec) const {
-    cnt.sphere_tests++;
-    const rt_prim& q = s->prims[idx];
-    const Vec center(q.f[0], q.f[1], q.f[2]);
-    const R radius = q.f[3];
+  // The quadratic of hitable.rs:50-61: discriminant and both roots (the roots are meaningless when it is not positive).
+  static void sphere_roots(Vec center, R radius, const Ray<P>& r, R& discriminant, R& near_t, R& far_t) {
     const Vec oc = r.origin() - center;
     const R a = dot<P>(r.direction(), r.direction());
     const R b = dot<P>(oc, r.direction());
-    R discriminant, near_t, far_t;
     if (sizeof(R) == 4) {
       // fp32 only, not in the reference: b*b - a*c cancels badly when the origin is far from a small sphere (at 2000
       // units from a sphere of radius 2.4 its absolute error is a tenth of the discriminant's whole range, so grazing
@@ -261,6 +256,16 @@ template <class P> struct World {
       near_t = (-b - sq) / a;
       far_t = (-b + sq) / a;
     }
+  }
+
+  // ---- hitable.rs:49-84 Sphere::hit ----
+  bool sphere_hit(int idx, const Ray<P>& r, R t_min, R t_max, HitRecord<R>& rec) const {
+    cnt.sphere_tests++;
+    const rt_prim& q = s->prims[idx];
+    const Vec center(q.f[0], q.f[1], q.f[2]);
+    const R radius = q.f[3];
+    R discriminant, near_t, far_t;
+    sphere_roots(center, radius, r, discriminant, near_t, far_t);
     if (discriminant > R(0)) {
       for (int root = 0; root < 2; ++root) {
         const R temp = root == 0 ? near_t : far_t;
@@ -567,27 +572,59 @@ template <class P> struct World {
     Vec local(Vec a) const { return scalar<R>(a.x) * u + scalar<R>(a.y) * v + scalar<R>(a.z) * w; }
   };
 
-  // ---- hitable.rs:245-254 XZRect::pdf_value ----
+  // ---- Hitable::pdf_value (hitable.rs:23-25, 245-254) of a light shape ----
+  // Only XZRect overrides it in the reference (hitable.rs:245-254).  The XY and YZ rects get the same formula with
+  // their own axes; the sphere gets the book's ("Ray Tracing: The Rest of Your Life", Sphere::pdf_value): uniform over
+  // the cone the sphere subtends, zero for directions that miss it.  Those are this build's additions: the reference
+  // has no code for them.
   R light_pdf_value(const rt_light& lt, Vec o, Vec v) const {
     cnt.light_tests++;
-    const R x0 = lt.f[0], x1 = lt.f[1], z0 = lt.f[2], z1 = lt.f[3], k = lt.f[4];
+    if (lt.type == RT_LIGHT_SPHERE) {
+      const Vec center(lt.f[0], lt.f[1], lt.f[2]);
+      const R radius = lt.f[3];
+      R discriminant, near_t, far_t;
+      sphere_roots(center, radius, Ray<P>(o, v), discriminant, near_t, far_t);
+      if (!(discriminant > R(0))) return 0;
+      const bool near_ok = near_t < real_max() && near_t > R(0.001), far_ok = far_t < real_max() && far_t > R(0.001);
+      if (!near_ok && !far_ok) return 0;
+      const R cos_theta_max = std::sqrt(R(1) - radius * radius / squared_length<P>(center - o));
+      const R solid_angle = R(2) * pi<R>() * (R(1) - cos_theta_max);
+      return R(1) / solid_angle;
+    }
+    // the fixed axis C and the in-plane axes A, B in constructor order (hitable.rs:151, 204, 278)
+    const int C = lt.type == RT_LIGHT_XZ_RECT ? 1 : (lt.type == RT_LIGHT_XY_RECT ? 2 : 0);
+    const int A = lt.type == RT_LIGHT_YZ_RECT ? 1 : 0;
+    const int B = lt.type == RT_LIGHT_XY_RECT ? 1 : 2;
+    const R a0 = lt.f[0], a1 = lt.f[1], b0 = lt.f[2], b1 = lt.f[3], k = lt.f[4];
     // XZRect::hit(&Ray::new(o, v), 0.001, f64::MAX), hitable.rs:217-236
-    const R t = (k - o.y) / v.y;
+    const R t = (k - o[C]) / v[C];
     if (t < R(0.001) || t > real_max()) return 0;
-    const R x = o.x + t * v.x;
-    const R z = o.z + t * v.z;
-    if (x < x0 || x > x1 || z < z0 || z > z1) return 0;
-    const Vec normal(0, 1, 0);
-    const R area = (x1 - x0) * (z1 - z0);
+    const R a = o[A] + t * v[A];
+    const R b = o[B] + t * v[B];
+    if (a < a0 || a > a1 || b < b0 || b > b1) return 0;
+    const R area = (a1 - a0) * (b1 - b0);
     const R distance_squared = t * t * squared_length<P>(v);
-    const R cosine = std::fabs(dot<P>(v, normal) / length<P>(v));
+    const R cosine = std::fabs(v[C] / length<P>(v));  // dot(v, normal) with the rect's own axis normal
     return distance_squared / (cosine * area);
   }
 
-  // ---- hitable.rs:256-264 XZRect::random ----
+  // ---- Hitable::random (hitable.rs:27-29, 256-264) of a light shape ----
   static Vec light_random(const rt_light& lt, Vec o, R xi1, R xi2) {
-    const R x0 = lt.f[0], x1 = lt.f[1], z0 = lt.f[2], z1 = lt.f[3], k = lt.f[4];
-    const Vec random_point(x0 + xi1 * (x1 - x0), k, z0 + xi2 * (z1 - z0));
+    if (lt.type == RT_LIGHT_SPHERE) {
+      // the book's Sphere::random: a direction inside the cone towards the sphere
+      const Vec center(lt.f[0], lt.f[1], lt.f[2]);
+      const R radius = lt.f[3];
+      const Vec direction = center - o;
+      const R distance_squared = squared_length<P>(direction);
+      const ONB uvw = ONB::build_from_w(direction);
+      const R z = R(1) + xi2 * (std::sqrt(R(1) - radius * radius / distance_squared) - R(1));
+      const R phi = R(2) * pi<R>() * xi1;
+      const R sxy = std::sqrt(R(1) - z * z);
+      return uvw.local(Vec(std::cos(phi) * sxy, std::sin(phi) * sxy, z));
+    }
+    const R a0 = lt.f[0], a1 = lt.f[1], b0 = lt.f[2], b1 = lt.f[3], k = lt.f[4];
+    const R a = a0 + xi1 * (a1 - a0), b = b0 + xi2 * (b1 - b0);
+    const Vec random_point = lt.type == RT_LIGHT_XZ_RECT ? Vec(a, k, b) : (lt.type == RT_LIGHT_XY_RECT ? Vec(a, b, k) : Vec(k, a, b));
     return random_point - o;
   }
 
@@ -640,14 +677,26 @@ template <class P> struct World {
       Vec dir;
       R pdf_val;
       if (s->n_lights > 0) {
-        const rt_light& lt = s->lights[0];
+        // HitablePDF over the light shapes.  The reference samples one shape (main.rs:177-178).  With several, the
+        // shapes form a list whose random() picks one uniformly and whose pdf_value() is the mean of theirs (the
+        // book's HitableList; the reference's list keeps the defaults 0.0 and (1,0,0), hitable.rs:23-29): one more
+        // draw, counter (pixel, sample, depth, 8192), word 0, picks the shape.
+        int pick = 0;
+        if (s->n_lights > 1) {
+          uint32_t w2[4];
+          smp.draw((uint32_t)depth, 8192u, w2);
+          pick = (int)(((uint64_t)w2[0] * (uint64_t)s->n_lights) >> 32);
+        }
         // pdf.rs:69-75: gen::<bool>() is the top bit of a fresh 32-bit word.
-        if (w[1] >> 31) dir = light_random(lt, rec.p, xi1, xi2);
+        if (w[1] >> 31) dir = light_random(s->lights[pick], rec.p, xi1, xi2);
         else dir = uvw.local(random_cosine_direction(xi1, xi2));
         // pdf.rs:65-67, 19-26
         const R cosine = dot<P>(unit<P>(dir), uvw.w);
         const R cos_pdf = cosine > R(0) ? cosine / pi<R>() : R(0);
-        pdf_val = R(0.5) * light_pdf_value(lt, rec.p, dir) + R(0.5) * cos_pdf;
+        R light_pdf = 0;
+        for (int k = 0; k < s->n_lights; ++k) light_pdf += light_pdf_value(s->lights[k], rec.p, dir);
+        if (s->n_lights > 1) light_pdf /= R(s->n_lights);
+        pdf_val = R(0.5) * light_pdf + R(0.5) * cos_pdf;
       } else {
         dir = uvw.local(random_cosine_direction(xi1, xi2));
         const R cosine = dot<P>(unit<P>(dir), uvw.w);
@@ -948,6 +997,19 @@ void orc_camera_ray(const rt_camera* cam, double s, double t, const rt_render_pa
 void orc_random_cosine_direction(double r1, double r2, double out[3]) {
   const V3<double> v = World<PolicyF64>::random_cosine_direction(r1, r2);
   out[0] = v.x; out[1] = v.y; out[2] = v.z;
+}
+
+void orc_light_pdf_value(const rt_light* light, const double o[3], const double* dirs, size_t n, double* out) {
+  const World<PolicyF64> world(nullptr);
+  for (size_t i = 0; i < n; ++i)
+    out[i] = world.light_pdf_value(*light, V3<double>(o[0], o[1], o[2]), V3<double>(dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2]));
+}
+
+void orc_light_random(const rt_light* light, const double o[3], const double* xi, size_t n, double* out_dirs) {
+  for (size_t i = 0; i < n; ++i) {
+    const V3<double> d = World<PolicyF64>::light_random(*light, V3<double>(o[0], o[1], o[2]), xi[2 * i], xi[2 * i + 1]);
+    out_dirs[3 * i] = d.x; out_dirs[3 * i + 1] = d.y; out_dirs[3 * i + 2] = d.z;
+  }
 }
 
 void orc_onb_local(const double n[3], const double a[3], double out[3]) {

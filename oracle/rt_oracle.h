@@ -63,6 +63,9 @@ void orc_camera_ray(const rt_camera* cam, double s, double t, const rt_render_pa
                     int pixel, int sample, int mode, double out_o[3], double out_d[3]);
 void orc_random_cosine_direction(double r1, double r2, double out[3]);
 void orc_onb_local(const double n[3], const double a[3], double out[3]);
+/* Hitable::pdf_value(o, dir) and Hitable::random(o) of one light shape (f64), for n directions / n pairs of uniforms. */
+void orc_light_pdf_value(const rt_light* light, const double o[3], const double* dirs, size_t n, double* out);
+void orc_light_random(const rt_light* light, const double o[3], const double* xi, size_t n, double* out_dirs);
 
 #ifdef __cplusplus
 }

@@ -25,6 +25,7 @@ RT_MAT_LAMBERTIAN, RT_MAT_DIFFUSE_LIGHT, RT_MAT_METAL, RT_MAT_DIELECTRIC, RT_MAT
 RT_TEX_CONSTANT, RT_TEX_CHECKER, RT_TEX_NOISE = 0, 1, 2
 RT_SKY_BLACK, RT_SKY_GRADIENT = 0, 1
 RT_SHARD_SAMPLES, RT_SHARD_TILES = 0, 1
+RT_LIGHT_XZ_RECT, RT_LIGHT_XY_RECT, RT_LIGHT_YZ_RECT, RT_LIGHT_SPHERE = 0, 1, 2, 3
 RT_MULTI_NO_RCCL = 1
 
 
@@ -166,6 +167,8 @@ def lib():
     sig("rtb_bvh_node", C.c_int, vp, C.POINTER(C.c_int), C.c_int)
     sig("rtb_light_xz_rect", C.c_int, vp, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double)
     sig("rtb_light_from_world", C.c_int, vp, C.c_int)
+    sig("rtb_light_add", C.c_int, vp, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double)
+    sig("rtb_lights_from_world", C.c_int, vp, C.c_int)
     sig("rtb_flatten", C.c_int, vp, C.c_int, C.POINTER(rt_scene))
     _lib = L
     return L

@@ -128,7 +128,9 @@ struct DevScene {
   int stack_mode;
   int stack_depth;  // entries per lane of the traversal stack that the deepest walk can need
   int stack_lds;    // of which this many live in LDS
-  rt_light light;
+  rt_light light;          // the first shape (the only one in the reference's own case: one XZRect)
+  const rt_light* lights;  // all of them
+  int light_general;       // several shapes, or a shape other than an XZRect: the general HitablePDF code
 };
 
 static_assert(sizeof(rt_prim) == 32 && sizeof(ScanNode) == 64, "record sizes the byte-offset loads assume");
@@ -1059,6 +1061,56 @@ __device__ __forceinline__ F3 reflect3(F3 v, F3 n) {
 
 #define RT_INV_PI_F 0.31830988618379067154f
 
+// Hitable::random / Hitable::pdf_value of a light shape other than the reference's single XZRect (which shade_vertex
+// has inline): XY and YZ rects with XZRect's formulas (hitable.rs:245-264) on their own axes, spheres with the
+// pdf_value/random of "Ray Tracing: The Rest of Your Life" (a cone towards the sphere).  The reference has no code
+// for these; the oracle restates the same formulas.
+__device__ __forceinline__ F3 light_random_general(int type, const float* f, F3 o, float xi1, float xi2) {
+  // rect: a point of the rect minus o
+  const float a = fmaf(xi1, f[1] - f[0], f[0]), b = fmaf(xi2, f[3] - f[2], f[2]), k = f[4];
+  const F3 pt = type == RT_LIGHT_XZ_RECT ? f3(a, k, b) : (type == RT_LIGHT_XY_RECT ? f3(a, b, k) : f3(k, a, b));
+  const F3 rect_dir = f3(pt.x - o.x, pt.y - o.y, pt.z - o.z);
+  // sphere: a direction inside the cone it subtends
+  const F3 dc = f3(f[0] - o.x, f[1] - o.y, f[2] - o.z);
+  const float d2 = dot3(dc, dc);
+  const F3 w = dc * fast_rsq(d2);
+  const bool big_x = fabsf(w.x) > 0.9f;
+  const F3 ax = big_x ? f3(0.0f, 1.0f, 0.0f) : f3(1.0f, 0.0f, 0.0f);
+  const F3 v = unit3(cross3(w, ax));
+  const F3 u = cross3(w, v);
+  const float z = 1.0f + xi2 * (fast_sqrt(fmaxf(0.0f, 1.0f - f[3] * f[3] * fast_rcp(d2))) - 1.0f);
+  const float sxy = fast_sqrt(fmaxf(0.0f, 1.0f - z * z));
+  const float cx = __builtin_amdgcn_cosf(xi1) * sxy, cy = __builtin_amdgcn_sinf(xi1) * sxy;
+  const F3 sph_dir = f3(fmaf(z, w.x, fmaf(cy, v.x, cx * u.x)), fmaf(z, w.y, fmaf(cy, v.y, cx * u.y)), fmaf(z, w.z, fmaf(cy, v.z, cx * u.z)));
+  return sel3(type == RT_LIGHT_SPHERE, sph_dir, rect_dir);
+}
+// `type` and `f` are wave-uniform here (the caller loops over the shapes).
+__device__ __forceinline__ float light_pdf_general(int type, const float* f, F3 o, F3 v, float dlen2, float inv_len) {
+  if (type == RT_LIGHT_SPHERE) {
+    const F3 oc = f3(o.x - f[0], o.y - f[1], o.z - f[2]);
+    const float inv_a = fast_rcp(dlen2);
+    const float k = dot3(oc, v) * inv_a;
+    const F3 l = f3(fmaf(-k, v.x, oc.x), fmaf(-k, v.y, oc.y), fmaf(-k, v.z, oc.z));
+    const float h = fmaf(f[3], f[3], -dot3(l, l));
+    const float sq = fast_sqrt(h * inv_a);
+    const float t_near = -k - sq, t_far = -k + sq;
+    const bool hit = (h > 0.0f) & (((t_near < 3.402823466e+38f) & (t_near > 0.001f)) | ((t_far < 3.402823466e+38f) & (t_far > 0.001f)));
+    const float cos_max = fast_sqrt(fmaxf(0.0f, 1.0f - f[3] * f[3] * fast_rcp(dot3(oc, oc))));
+    const float solid = 6.28318530717958647692f * (1.0f - cos_max);
+    return hit ? fast_rcp(solid) : 0.0f;
+  }
+  const float oc = type == RT_LIGHT_XZ_RECT ? o.y : (type == RT_LIGHT_XY_RECT ? o.z : o.x);
+  const float vc = type == RT_LIGHT_XZ_RECT ? v.y : (type == RT_LIGHT_XY_RECT ? v.z : v.x);
+  const float oa = type == RT_LIGHT_YZ_RECT ? o.y : o.x, va = type == RT_LIGHT_YZ_RECT ? v.y : v.x;
+  const float ob = type == RT_LIGHT_XY_RECT ? o.y : o.z, vb = type == RT_LIGHT_XY_RECT ? v.y : v.z;
+  const float t = (f[4] - oc) * fast_rcp(vc);
+  const float la = fmaf(t, va, oa), lb = fmaf(t, vb, ob);
+  const bool miss = (t < 0.001f) | (t > 3.402823466e+38f) | (la < f[0]) | (la > f[1]) | (lb < f[2]) | (lb > f[3]);
+  const float area = (f[1] - f[0]) * (f[3] - f[2]);
+  const float cosine = fabsf(vc * inv_len);
+  return miss ? 0.0f : (t * t * dlen2) * fast_rcp(cosine * area);
+}
+
 // What one path vertex comes to: color() of main.rs:165-209 for the hit `h` of `ray`.
 struct Shaded {
   F3 radiance;  // what this vertex adds to the sample (weight x emitted or sky), before de_nan
@@ -1123,8 +1175,21 @@ __device__ __forceinline__ Shaded shade_vertex(const DevScene& S, const float4* 
   const F3 uu = cross3(ww, vv);
   const bool pick_light = (S.n_lights > 0) & ((w.y >> 31) != 0u);  // MixturePDF's coin, pdf.rs:70
   // XZRect::random, hitable.rs:256-264
-  const F3 dir_light = f3(fmaf(xi1, S.light.f[1] - S.light.f[0], S.light.f[0]) - sf.p.x, S.light.f[4] - sf.p.y,
-                          fmaf(xi2, S.light.f[3] - S.light.f[2], S.light.f[2]) - sf.p.z);
+  F3 dir_light = f3(fmaf(xi1, S.light.f[1] - S.light.f[0], S.light.f[0]) - sf.p.x, S.light.f[4] - sf.p.y,
+                    fmaf(xi2, S.light.f[3] - S.light.f[2], S.light.f[2]) - sf.p.z);
+  if (GENERAL != 0 && S.light_general) {
+    // HitablePDF over a list of shapes: random() picks one uniformly; counter (pixel, sample, depth, 8192), word 0
+    rt_light lt = S.light;
+    if (S.n_lights > 1) {
+      const U4 lw = philox4x32_10(pixel_id, sample, (unsigned)depth, 8192u, key0, key1);
+      const unsigned pick = (unsigned)(((unsigned long long)lw.x * (unsigned long long)(unsigned)S.n_lights) >> 32);
+      const float4* src = (const float4*)((const char*)S.lights + (pick << 5));
+      const float4 l0 = src[0], l1 = src[1];
+      __builtin_memcpy((char*)&lt, &l0, 16);
+      __builtin_memcpy((char*)&lt + 16, &l1, 16);
+    }
+    dir_light = light_random_general(lt.type, lt.f, sf.p, xi1, xi2);
+  }
   // random_cosine_direction, main.rs:239-249 (x and y keep the source's factor 2);
   // v_sin/v_cos take their argument in turns, so phi = 2*pi*r1 is r1 turns.
   const float cz = fast_sqrt(1.0f - xi2);
@@ -1146,7 +1211,19 @@ __device__ __forceinline__ Shaded shade_vertex(const DevScene& S, const float4* 
     const bool miss = (t < 0.001f) | (t > 3.402823466e+38f) | (lx < S.light.f[0]) | (lx > S.light.f[1]) | (lz < S.light.f[2]) | (lz > S.light.f[3]);
     const float area = (S.light.f[1] - S.light.f[0]) * (S.light.f[3] - S.light.f[2]);
     const float cosine = fabsf(dir.y * inv_len);
-    const float lp = miss ? 0.0f : (t * t * dlen2) * fast_rcp(cosine * area);
+    float lp = miss ? 0.0f : (t * t * dlen2) * fast_rcp(cosine * area);
+    if (GENERAL != 0 && S.light_general) {
+      // pdf_value() of the list: the mean of the shapes' (a wave-uniform loop: the records arrive by scalar load)
+      lp = 0.0f;
+      for (int k = 0; k < S.n_lights; ++k) {
+        const u32x8 v8 = *(const RT_CONSTANT_AS u32x8*)((const RT_CONSTANT_AS char*)S.lights + (unsigned)k * 32u);
+        rt_light lk;
+        __builtin_memcpy(&lk, &v8, sizeof(lk));
+        lp += light_pdf_general(lk.type, lk.f, sf.p, dir, dlen2, inv_len);
+        if (STATS && k > 0) cnt.light_tests += scatters;
+      }
+      lp *= fast_rcp((float)S.n_lights);
+    }
     pdf_val = 0.5f * lp + 0.5f * pdf_val;
   }
   // material.rs:76-82
@@ -1987,6 +2064,7 @@ struct rt_ctx {
   void* d_materials;
   void* d_textures;
   void* d_perlins;
+  void* d_lights;
   unsigned long long* d_stats;
   unsigned* d_queue;    // the work-item counter of render_kernel
   int n_cus;
@@ -2014,7 +2092,7 @@ int hip_fail(hipError_t e, const char* what) {
   } while (0)
 
 void free_scene(rt_ctx* ctx) {
-  void** ptrs[] = {&ctx->d_scan, &ctx->d_prims, &ctx->d_dprims, &ctx->d_leaf_box, &ctx->d_bnodes, &ctx->d_bnodes4, &ctx->d_sub_root_ref, &ctx->d_box6_index, &ctx->d_box6_recs, &ctx->d_prim_rank, &ctx->d_objects, &ctx->d_materials, &ctx->d_textures, &ctx->d_perlins};
+  void** ptrs[] = {&ctx->d_scan, &ctx->d_prims, &ctx->d_dprims, &ctx->d_leaf_box, &ctx->d_bnodes, &ctx->d_bnodes4, &ctx->d_sub_root_ref, &ctx->d_box6_index, &ctx->d_box6_recs, &ctx->d_prim_rank, &ctx->d_objects, &ctx->d_materials, &ctx->d_textures, &ctx->d_perlins, &ctx->d_lights};
   for (size_t i = 0; i < sizeof(ptrs) / sizeof(ptrs[0]); ++i) {
     if (*ptrs[i]) (void)hipFree(*ptrs[i]);
     *ptrs[i] = nullptr;
@@ -2033,12 +2111,17 @@ int validate_scene(const rt_scene* s) {
   if (s->n_materials >= (1 << 19) || s->n_prims >= (1 << 23)) return rt::set_error(RT_ERR_UNSUPPORTED, "too many materials or primitives");
   if ((s->n_textures > 0 && !s->textures) || (s->n_objects > 0 && !s->objects) || (s->n_perlins > 0 && !s->perlins) || (s->n_lights > 0 && !s->lights))
     return rt::set_error(RT_ERR_INVALID, "a count is positive but its array pointer is null");
-  if (s->n_lights < 0 || s->n_lights > 1) return rt::set_error(RT_ERR_UNSUPPORTED, "n_lights must be 0 or 1");
-  if (s->n_lights == 1) {
-    const rt_light& l = s->lights[0];
-    if (l.type != RT_LIGHT_XZ_RECT) return rt::set_error(RT_ERR_UNSUPPORTED, "light type must be RT_LIGHT_XZ_RECT");
-    // XZRect::pdf_value divides by the rect's area (hitable.rs:249-251)
-    if (!(l.f[0] < l.f[1]) || !(l.f[2] < l.f[3])) return rt::set_error(RT_ERR_INVALID, "light rect must have x0 < x1 and z0 < z1");
+  if (s->n_lights < 0 || s->n_lights > RT_MAX_LIGHTS) return rt::set_error(RT_ERR_UNSUPPORTED, "n_lights must be 0 .. RT_MAX_LIGHTS");
+  for (int i = 0; i < s->n_lights; ++i) {
+    const rt_light& l = s->lights[i];
+    if (l.type == RT_LIGHT_SPHERE) {
+      if (!(l.f[3] > 0.0f)) return rt::set_error(RT_ERR_INVALID, "light sphere must have a positive radius");
+    } else if (l.type == RT_LIGHT_XZ_RECT || l.type == RT_LIGHT_XY_RECT || l.type == RT_LIGHT_YZ_RECT) {
+      // XZRect::pdf_value divides by the rect's area (hitable.rs:249-251)
+      if (!(l.f[0] < l.f[1]) || !(l.f[2] < l.f[3])) return rt::set_error(RT_ERR_INVALID, "light rect must have a0 < a1 and b0 < b1");
+    } else {
+      return rt::set_error(RT_ERR_INVALID, "unknown light type");
+    }
   }
   for (int i = 0; i < s->n_textures; ++i) {
     const rt_texture& t = s->textures[i];
@@ -2827,7 +2910,11 @@ int rt_upload_scene(rt_ctx* ctx, const rt_scene* s) {
   d.n_dprims = (int)dprims.size();
   d.n_lights = s->n_lights;
   if (s->n_lights > 0) d.light = s->lights[0];
-  ctx->general = textured ? 2 : ((!B.media.empty() || (mat_mask & ~((1 << RT_MAT_LAMBERTIAN) | (1 << RT_MAT_DIFFUSE_LIGHT))) != 0) ? 1 : 0);
+  if ((rc = upload(&ctx->d_lights, s->lights, (size_t)s->n_lights)) != RT_OK) return rc;
+  d.lights = (const rt_light*)ctx->d_lights;
+  d.light_general = (s->n_lights > 1 || (s->n_lights == 1 && s->lights[0].type != RT_LIGHT_XZ_RECT)) ? 1 : 0;
+  // (the general light code is compiled into the builds 1 and 2 only, so that the Cornell build keeps its registers)
+  ctx->general = textured ? 2 : d.light_general ? 1 : ((!B.media.empty() || (mat_mask & ~((1 << RT_MAT_LAMBERTIAN) | (1 << RT_MAT_DIFFUSE_LIGHT))) != 0) ? 1 : 0);
   ctx->has_scene = true;
   return RT_OK;
 }

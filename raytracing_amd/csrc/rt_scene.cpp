@@ -620,6 +620,41 @@ int rtb_light_from_world(rt_builder* b, int world_list) {
   return found;
 }
 
+int rtb_light_add(rt_builder* b, int type, double a, double bb, double c, double d, double e) {
+  if (type < RT_LIGHT_XZ_RECT || type > RT_LIGHT_SPHERE) return rt::set_error(RT_ERR_INVALID, "rtb_light_add: unknown light type");
+  if (b->tables.lights.size() >= (size_t)RT_MAX_LIGHTS) return rt::set_error(RT_ERR_UNSUPPORTED, "rtb_light_add: more than RT_MAX_LIGHTS shapes");
+  rt_light l;
+  std::memset(&l, 0, sizeof(l));
+  l.type = type;
+  l.f[0] = (float)a; l.f[1] = (float)bb; l.f[2] = (float)c; l.f[3] = (float)d; l.f[4] = (float)e;
+  b->tables.lights.push_back(l);
+  return (int)b->tables.lights.size();
+}
+
+int rtb_lights_from_world(rt_builder* b, int world_list) {
+  if (bad_hitable(b, world_list) || b->hitables[world_list]->kind() != rt::Hitable::HITABLE_LIST)
+    return rt::set_error(RT_ERR_INVALID, "rtb_lights_from_world: world must be a HitableList handle");
+  const rt::HitableList* world = static_cast<const rt::HitableList*>(b->hitables[world_list].get());
+  b->tables.lights.clear();
+  for (const rt::HitablePtr& h : world->list) {
+    if (b->tables.lights.size() >= (size_t)RT_MAX_LIGHTS) break;
+    if (h->kind() == rt::Hitable::SPHERE) {
+      const rt::Sphere* sp = static_cast<const rt::Sphere*>(h.get());
+      if (b->tables.materials[(size_t)sp->material.id].type != RT_MAT_DIFFUSE_LIGHT || !(sp->radius > 0.0)) continue;
+      (void)rtb_light_add(b, RT_LIGHT_SPHERE, sp->center.x, sp->center.y, sp->center.z, sp->radius, 0.0);
+      continue;
+    }
+    const rt::Rect* rect = nullptr;
+    if (h->kind() == rt::Hitable::XY_RECT || h->kind() == rt::Hitable::XZ_RECT || h->kind() == rt::Hitable::YZ_RECT) rect = static_cast<const rt::Rect*>(h.get());
+    else if (h->kind() == rt::Hitable::FLIP_NORMALS) rect = static_cast<const rt::FlipNormals*>(h.get())->rect.get();
+    if (!rect || b->tables.materials[(size_t)rect->material.id].type != RT_MAT_DIFFUSE_LIGHT) continue;
+    if (!(rect->a0 < rect->a1) || !(rect->b0 < rect->b1)) continue;
+    const int type = rect->axis == 2 ? RT_LIGHT_XY_RECT : (rect->axis == 1 ? RT_LIGHT_XZ_RECT : RT_LIGHT_YZ_RECT);
+    (void)rtb_light_add(b, type, rect->a0, rect->a1, rect->b0, rect->b1, rect->k);
+  }
+  return (int)b->tables.lights.size();
+}
+
 int rtb_flatten(rt_builder* b, int world_list, rt_scene* out) {
   if (!out) return rt::set_error(RT_ERR_INVALID, "rtb_flatten: null out");
   if (bad_hitable(b, world_list) || b->hitables[world_list]->kind() != rt::Hitable::HITABLE_LIST)

@@ -91,6 +91,22 @@ class Scene(object):
         """The XZRect that color() gives to HitablePDF (main.rs:177-178)."""
         return check(_lib.lib().rtb_light_xz_rect(self._b, x0, x1, z0, z1, k))
 
+    def light_add(self, kind, a, b, c, d, e=0.0):
+        """Appends a shape to the list HitablePDF samples (beyond the reference,
+        whose color() samples one XZRect): kind is "xz_rect", "xy_rect", "yz_rect"
+        (a0, a1, b0, b1, k in the constructor's order) or "sphere" (cx, cy, cz, r).
+        Returns the number of shapes registered."""
+        types = {"xz_rect": _lib.RT_LIGHT_XZ_RECT, "xy_rect": _lib.RT_LIGHT_XY_RECT, "yz_rect": _lib.RT_LIGHT_YZ_RECT,
+                 "sphere": _lib.RT_LIGHT_SPHERE}
+        return check(_lib.lib().rtb_light_add(self._b, types[kind], a, b, c, d, e))
+
+    def lights_from_world(self, world):
+        """Registers every emissive rect (XY, XZ, YZ, bare or flipped) and sphere of
+        `world` as a light shape, replacing any set before.  Returns the count."""
+        if world.scene is not self:
+            raise ValueError("world belongs to another Scene")
+        return check(_lib.lib().rtb_lights_from_world(self._b, world.handle))
+
     def light_from_world(self, world):
         """Takes the light shape from the scene: the first emissive XZRect of
         `world` (bare or under FlipNormals).  Returns how many there are."""

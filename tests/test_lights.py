@@ -1,0 +1,148 @@
+"""Light shapes for HitablePDF beyond the reference's single XZRect (pdf.rs:33-50,
+hitable.rs:245-264): XY/YZ rects, spheres, and lists of shapes.  The reference has
+no code for these, so nothing of it pins them; what is checked is that each
+shape's pdf_value and random belong together (the pdf integrates to one over the
+directions that reach the shape, and random's directions have that density), that
+the reference's own case is untouched, and that device and oracle agree."""
+import numpy as np
+import pytest
+
+from raytracing_amd import Scene, _lib, make_params, scenes
+from raytracing_amd import scene as S
+
+
+def _light(kind, *f):
+    lt = _lib.rt_light()
+    lt.type = {"xz": _lib.RT_LIGHT_XZ_RECT, "xy": _lib.RT_LIGHT_XY_RECT, "yz": _lib.RT_LIGHT_YZ_RECT, "sphere": _lib.RT_LIGHT_SPHERE}[kind]
+    for k, v in enumerate(f):
+        lt.f[k] = v
+    return lt
+
+
+SHAPES = [
+    ("xz", (213.0, 343.0, 227.0, 332.0, 554.0), (278.0, 100.0, 250.0)),
+    ("xy", (3.0, 5.0, 1.0, 3.0, -2.0), (2.0, 0.5, 4.0)),
+    ("yz", (-1.0, 2.0, 0.0, 4.0, 10.0), (1.0, 1.0, 1.0)),
+    ("sphere", (0.0, 3.0, 0.0, 1.0), (4.0, 0.5, 2.0)),
+    ("sphere", (10.0, -2.0, 5.0, 4.0), (0.0, 0.0, 0.0)),
+]
+
+
+@pytest.mark.parametrize("kind,f,o", SHAPES)
+def test_pdf_value_and_random_of_a_shape_belong_together(orc, kind, f, o):
+    lt = _light(kind, *f)
+    rng = np.random.RandomState(5)
+    # (1) the pdf integrates to one over the sphere of directions
+    n = 400000
+    d = rng.normal(size=(n, 3))
+    pdf = orc.light_pdf_value(lt, o, d)
+    hit = pdf > 0
+    integral = pdf.mean() * 4.0 * np.pi
+    se = pdf.std() / np.sqrt(n) * 4.0 * np.pi
+    assert abs(integral - 1.0) < max(5 * se, 0.01), (integral, se)
+    # (2) random()'s directions all reach the shape, and E[1/pdf] under random() is the solid angle the shape covers
+    xi = rng.rand(100000, 2)
+    dirs = orc.light_random(lt, o, xi)
+    p2 = orc.light_pdf_value(lt, o, dirs)
+    assert (p2 > 0).mean() > 0.999
+    solid_from_samples = (1.0 / p2[p2 > 0]).mean()
+    solid_from_hits = hit.mean() * 4.0 * np.pi
+    assert abs(solid_from_samples - solid_from_hits) < 0.03 * solid_from_hits + 5 * 4 * np.pi * np.sqrt(hit.mean() / n)
+    # (3) scaling the direction does not change the pdf (it is a density over directions)
+    assert np.allclose(orc.light_pdf_value(lt, o, dirs[:1000] * 3.5), p2[:1000], rtol=1e-9)
+
+
+def test_one_xz_rect_through_the_list_code_is_the_reference_case(orc, cornell):
+    """The Cornell box with its light registered once (the reference's case) and
+    the same rect registered through rtb_light_add: identical f64 images."""
+    p = make_params(40, 40, 8, seed=11)
+    a, _ = orc.render(cornell.flat, cornell.camera.c, p, mode=orc.ORC_F64)
+    with Scene(0x5EED0001) as sc:
+        cam, world = scenes.cornell_box_scene(1.0)
+        assert sc.light_add("xz_rect", *scenes.MAIN_RS_LIGHT_SHAPE) == 1
+        flat = sc.flatten(world)
+        b, _ = orc.render(flat, cam.c, p, mode=orc.ORC_F64)
+    assert np.array_equal(a, b)
+
+
+def _two_light_room():
+    """The Cornell box with a second, YZ light on the red wall and an emissive sphere."""
+    cam, world0 = scenes.cornell_box_scene(1.0)
+    glow = S.DiffuseLight.new(S.Texture.new_constant(S.scalar(6.0)))
+    items = list(world0.list) + [
+        S.YZRect.new(200.0, 350.0, 150.0, 400.0, 1.0, glow),  # just inside the right wall (x = 0), facing +x
+        S.Sphere.new(S.vec3(420.0, 420.0, 120.0), 40.0, glow),
+    ]
+    return cam, S.HitableList.new(items)
+
+
+def test_lights_from_world_collects_rects_and_spheres():
+    with Scene(3) as sc:
+        cam, world = _two_light_room()
+        assert sc.lights_from_world(world) == 3
+        flat = sc.flatten(world)
+    assert flat.n_lights == 3
+    assert [flat.lights[k].type for k in range(3)] == [_lib.RT_LIGHT_XZ_RECT, _lib.RT_LIGHT_YZ_RECT, _lib.RT_LIGHT_SPHERE]
+    assert [flat.lights[0].f[k] for k in range(5)] == list(scenes.MAIN_RS_LIGHT_SHAPE)
+    assert [flat.lights[2].f[k] for k in range(4)] == [420.0, 420.0, 120.0, 40.0]
+    with Scene(4) as sc:
+        cam, world = scenes.random_scene(1.5)
+        n = sc.lights_from_world(world)
+        assert 20 < n <= 64  # about a tenth of the 484 small spheres emit, plus the 50.0 emitter (scenes.rs:87-92)
+        assert sc.flatten(world).n_lights == n
+
+
+def test_light_list_lowers_the_variance_not_the_mean_in_f32_and_f64(orc):
+    """The three-light room: fp32 and f64 restatements agree on the same stream
+    (the list code is the same arithmetic in both), and sampling all three lights
+    gives a less noisy image than sampling the ceiling light alone."""
+    with Scene(3) as sc:
+        cam, world = _two_light_room()
+        sc.lights_from_world(world)
+        flat3 = sc.flatten(world)
+        p = make_params(32, 32, 64, seed=2)
+        a, a2 = orc.render(flat3, cam.c, p, mode=orc.ORC_F64)
+        b, _ = orc.render(flat3, cam.c, p, mode=orc.ORC_F32_FUSED)
+        assert np.isclose(a, b, rtol=5e-3, atol=5e-2).mean() > 0.9
+        var3 = (a2 / 64 - (a / 64) ** 2).mean()
+    with Scene(3) as sc:
+        cam, world = _two_light_room()
+        sc.light_xz_rect(*scenes.MAIN_RS_LIGHT_SHAPE)
+        flat1 = sc.flatten(world)
+        c, c2 = orc.render(flat1, cam.c, p, mode=orc.ORC_F64)
+        var1 = (c2 / 64 - (c / 64) ** 2).mean()
+    assert var3 < 0.8 * var1, (var3, var1)
+
+
+@pytest.mark.gpu
+def test_device_renders_the_three_light_room_like_the_oracle(gpu, orc):
+    from test_gpu_materials import _compare
+    with Scene(3) as sc:
+        cam, world = _two_light_room()
+        assert sc.lights_from_world(world) == 3
+        flat = sc.flatten(world)
+        _compare(gpu, orc, flat, cam, 48, 48, 128, same_frac=0.9)
+
+
+@pytest.mark.gpu
+def test_device_samples_the_random_scenes_emitters(gpu, orc):
+    """random_scene (scenes.rs:12-124) with every emissive sphere registered: a
+    list of dozens of sphere lights on the stack-traversal kernel, thin lens on."""
+    from test_gpu_materials import _compare
+    with Scene(31) as sc:
+        cam, world = scenes.random_scene(1.5)
+        assert sc.lights_from_world(world) > 20
+        flat = sc.flatten(world)
+        _compare(gpu, orc, flat, cam, 60, 40, 64, same_frac=0.75, energy_tol=0.05)
+
+
+@pytest.mark.gpu
+def test_device_single_light_of_another_type(gpu, orc):
+    """simple_light_scene (scenes.rs:227-273): its XYRect light as the one shape."""
+    from test_gpu_materials import _compare
+    with Scene(12) as sc:
+        cam, world = scenes.simple_light_scene(1.5)
+        assert sc.lights_from_world(world) == 1
+        flat = sc.flatten(world)
+        assert flat.lights[0].type == _lib.RT_LIGHT_XY_RECT
+        _compare(gpu, orc, flat, cam, 60, 40, 128, same_frac=0.75, energy_tol=0.05)
