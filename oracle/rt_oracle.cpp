@@ -9,8 +9,9 @@
  * recursive unpruned BvhNode::hit, HitableList with a shrinking t_max.
  *
  * Parity status: PARITY UNPINNED by the reference's own tests (it has none);
- * the single coarse pin is examples/cornell_box.png, checked in
- * tests/test_oracle_reference_image.py.  See rt_oracle.h.
+ * the single pin is examples/cornell_box.png, checked in tests/test_oracle.py
+ * (block means at 20x20 and 10x10 pixels, wall colour ratios) and, for the device,
+ * in tests/test_gpu_render.py.  See rt_oracle.h.
  *
  * Random numbers: the reference uses rand::thread_rng() (OS seeded); this
  * restatement draws from the Philox4x32-10 stream fixed in include/rt_abi.h so

@@ -147,3 +147,40 @@ def cornell_ray_batch(cornell, n, seed):
     o = np.concatenate(os_).astype(np.float32)
     d = np.concatenate(ds_).astype(np.float32)
     return o, d
+
+
+def reference_png_fine(sum_rgb, sumsq_rgb, spp, img8):
+    """Compares a 600x600 Cornell render with the reference's example PNG at 10x10
+    pixel blocks (tests/golden/cornell_box_png_blocks10.npz: block means and pixel
+    noise variance of examples/cornell_box.png).  sum/sumsq are the per-pixel
+    sample sums and sums of squares at `spp` samples, img8 the tonemapped image.
+
+    Returns (n_hat, diff, ratios): the PNG's sample count estimated from its noise
+    (the per-sample variance of our render, carried through the sqrt tonemap,
+    divided by the PNG's pixel noise variance, median over the smooth blocks);
+    the block-mean differences in 8-bit levels after allowing for the tonemap's
+    noise bias (E[sqrt(mean of N samples)] lies below sqrt(mean) by
+    255.99 var / (8 N x^1.5), more at our spp than at the PNG's); and the wall
+    colour ratios (PNG, ours) over the red-wall and green-wall blocks."""
+    g = np.load(os.path.join(GOLDEN, "cornell_box_png_blocks10.npz"))
+    mean10, noise10 = g["mean"].astype(np.float64), g["noise_var"].astype(np.float64)
+    x = np.asarray(sum_rgb, dtype=np.float64) / spp
+    var1 = np.maximum(np.asarray(sumsq_rgb, dtype=np.float64) / spp - x * x, 0.0)
+    blk = lambda a: a.reshape(60, 10, 60, 10, 3).mean(axis=(1, 3))  # noqa: E731
+    xs = np.clip(x, 1e-4, None)
+    pred1 = blk(255.99 ** 2 / (4.0 * xs) * var1)  # pixel noise variance in 8-bit levels at ONE sample per pixel
+    xm = blk(x)
+    smooth = (xm > 0.05) & (xm < 0.8) & (noise10 > 0.3)
+    n_hat = float(np.median(pred1[smooth] / np.maximum(noise10[smooth] - 1.0 / 12.0, 1e-3)))  # 1/12: the 8-bit rounding's own variance
+    bias = lambda n: np.where(x < 1.0, 255.99 * var1 / (8.0 * n * xs ** 1.5), 0.0)  # noqa: E731
+    corr = np.clip(bias(float(spp)) - bias(n_hat), 0.0, 5.0)
+    ours = blk(np.asarray(img8, dtype=np.float64) + corr)
+    diff = ours - mean10
+    green = (mean10[..., 1] > 1.6 * mean10[..., 0]) & (mean10[..., 1] > 40)
+    red = (mean10[..., 0] > 2.0 * mean10[..., 1]) & (mean10[..., 0] > 40)
+    ratios = {
+        "green_wall_g_over_r": (mean10[green, 1].sum() / mean10[green, 0].sum(), ours[green, 1].sum() / ours[green, 0].sum()),
+        "red_wall_r_over_g": (mean10[red, 0].sum() / mean10[red, 1].sum(), ours[red, 0].sum() / ours[red, 1].sum()),
+        "blocks": (int(green.sum()), int(red.sum())),
+    }
+    return n_hat, diff, ratios

@@ -21,3 +21,14 @@ assert img.shape == (600, 600, 3), img.shape
 blocks = img.reshape(30, 20, 30, 20, 3).mean(axis=(1, 3)).astype(np.float32)
 np.save(DST, blocks)
 print("wrote", DST, blocks.shape, float(blocks.mean()))
+
+# The finer fixture: per 10x10 block the mean, and the pixel noise variance estimated from horizontally adjacent
+# pixels (half the mean squared difference of the five disjoint pairs of each row, which a smooth gradient barely
+# enters).  The noise level is what lets a test estimate the PNG's unrecorded sample count.
+DST10 = os.path.join(os.path.dirname(os.path.abspath(__file__)), "cornell_box_png_blocks10.npz")
+mean10 = img.reshape(60, 10, 60, 10, 3).mean(axis=(1, 3)).astype(np.float32)
+pairs = img.reshape(600, 300, 2, 3)
+half_sq = 0.5 * (pairs[:, :, 0, :] - pairs[:, :, 1, :]) ** 2          # (600, 300, 3)
+noise10 = half_sq.reshape(60, 10, 60, 5, 3).mean(axis=(1, 3)).astype(np.float32)
+np.savez_compressed(DST10, mean=mean10, noise_var=noise10)
+print("wrote", DST10, mean10.shape, float(noise10.mean()))

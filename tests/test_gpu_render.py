@@ -282,6 +282,30 @@ def test_device_render_matches_reference_example_png(gpu, cornell, tmp_path):
     assert back[:10].max() == 0 and back[:, :10].max() == 0  # the black frame
 
 
+def test_device_render_matches_reference_example_png_at_fine_blocks(gpu, cornell):
+    """The same file at 10x10 blocks against a 4096-sample device render: the PNG's
+    sample count is estimated from its own noise and the tonemap's noise bias
+    allowed for (conftest.reference_png_fine), so what is left in the difference is
+    the PNG's own Monte Carlo noise (about 0.35 levels per block); and the colour
+    ratios of the two painted walls."""
+    from conftest import reference_png_fine
+    gpu.upload_scene(cornell.flat)
+    spp = 4096
+    s, s2 = gpu.render(cornell.camera, make_params(600, 600, spp, seed=0x5EED0002), want_sumsq=True)
+    n_hat, diff, ratios = reference_png_fine(s, s2, spp, gpu.tonemap(s, spp))
+    print("estimated spp of the reference PNG %.0f; block diff max %.2f rms %.3f mean %.3f; ratios %r" % (
+        n_hat, np.abs(diff).max(), np.sqrt((diff ** 2).mean()), diff.mean(), ratios))
+    # measured: estimate 982 (the reference at quality 1000 renders 8 x 125 samples), max 1.45, rms 0.26, mean 0.04,
+    # colour ratios equal to 2 parts in 10,000
+    assert 800 < n_hat < 1250, n_hat
+    assert np.abs(diff).max() < 2.0, np.abs(diff).max()
+    assert np.sqrt((diff ** 2).mean()) < 0.35, np.sqrt((diff ** 2).mean())
+    assert abs(diff.mean()) < 0.1, diff.mean()
+    for key in ("green_wall_g_over_r", "red_wall_r_over_g"):
+        png, ours = ratios[key]
+        assert abs(ours / png - 1.0) < 0.003, (key, png, ours)
+
+
 def test_render_large_image_low_spp(gpu, orc, cornell):
     """3840x2160 at 2 samples per pixel: 129,600 tiles, every index past 2^16,
     against the oracle on the same random stream."""

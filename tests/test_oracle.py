@@ -38,6 +38,24 @@ def test_oracle_matches_reference_example_render(orc, cornell):
     assert img[:10].max() == 0.0 and img[:, :10].max() == 0.0
 
 
+def test_oracle_matches_reference_example_render_at_fine_blocks(orc, cornell):
+    """The same PNG at 10x10 blocks, with its sample count estimated from its own
+    noise (about 800: the reference's thread split makes it a multiple of 8) and the
+    tonemap's noise bias allowed for, plus the colour of the two painted walls,
+    which pins the albedos and the interreflection independently of the exposure."""
+    from conftest import reference_png_fine
+    spp = 64
+    s, s2 = orc.render(cornell.flat, cornell.camera.c, make_params(600, 600, spp, seed=0x5EED0001), mode=orc.ORC_F64, n_threads=8)
+    n_hat, diff, ratios = reference_png_fine(s, s2, spp, orc.tonemap(s, spp))
+    assert 400 < n_hat < 1600, n_hat
+    assert np.abs(diff).max() < 9.0 and np.sqrt((diff ** 2).mean()) < 1.3 and abs(diff.mean()) < 0.5, (
+        np.abs(diff).max(), np.sqrt((diff ** 2).mean()), diff.mean())
+    assert ratios["blocks"][0] > 30 and ratios["blocks"][1] > 300
+    for key in ("green_wall_g_over_r", "red_wall_r_over_g"):
+        png, ours = ratios[key]
+        assert abs(ours / png - 1.0) < 0.015, (key, png, ours)
+
+
 def test_oracle_bvh_equals_list_traversal(orc, cornell):
     """BvhNode::hit (bvh.rs:197-228) and a flat HitableList over the same
     leaves (main.rs:109, commented alternative) must find the same nearest hit
