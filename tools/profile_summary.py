@@ -44,10 +44,10 @@ def main():
             k = k.split("(")[0]
             agg[k][row["Counter_Name"]] += float(row["Counter_Value"])
             launches[(k, tag)].add(row["Dispatch_Id"])
-    print("\n## PMC, one launch of the headline workload (bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-stats)")
+    print("\n## PMC, one launch of the headline workload (bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-stats --no-other-configs)")
     traffic = {}
     for k, counters in agg.items():
-        if "render_kernel" not in k and "reduce_slabs" not in k:
+        if "render_kernel" not in k and "render_stack_kernel" not in k and "reduce_slabs" not in k:
             continue
         n = max(len(v) for (kk, _), v in launches.items() if kk == k)
         print("\n%s   (%d launch%s)" % (k, n, "" if n == 1 else "es"))
