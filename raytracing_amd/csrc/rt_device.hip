@@ -1144,8 +1144,8 @@ __device__ __forceinline__ Shaded shade_vertex(const DevScene& S, const float4* 
   F3 color = f3(q.color[0], q.color[1], q.color[2]);
   if (STATS) cnt.hits += hit;
   // A checker or noise texture's colour comes at the top of the next trip (see there); until then it counts as white.
-  const bool textured = GENERAL == 2 && S.textured && hit && (q.flags & DP_TEXTURED);
-  if (GENERAL == 2) color = sel3(textured, f3(1.0f, 1.0f, 1.0f), color);
+  const bool textured = GENERAL >= 2 && S.textured && hit && (q.flags & DP_TEXTURED);
+  if (GENERAL >= 2) color = sel3(textured, f3(1.0f, 1.0f, 1.0f), color);
 
   // material.rs:197-203: a light emits towards the side its normal points to and never scatters.
   const bool is_light = mat_type == RT_MAT_DIFFUSE_LIGHT;
@@ -1157,7 +1157,7 @@ __device__ __forceinline__ Shaded shade_vertex(const DevScene& S, const float4* 
     const float t = 0.5f * (ud.y + 1.0f);
     sky = f3((1.0f - t) + t * 0.5f, (1.0f - t) + t * 0.7f, (1.0f - t) + t * 1.0f);
   }
-  const F3 le = sel3(emits, (GENERAL == 2) ? sel3(textured, f3(0, 0, 0), color) : color, sel3(hit, f3(0, 0, 0), sky));
+  const F3 le = sel3(emits, (GENERAL >= 2) ? sel3(textured, f3(0, 0, 0), color) : color, sel3(hit, f3(0, 0, 0), sky));
   out.radiance = f3(thr.x * le.x, thr.y * le.y, thr.z * le.z);  // what this vertex adds to the sample, before de_nan
 
   // Lambertian under MixturePDF(HitablePDF(light), CosinePDF(normal)), main.rs:173-197.
@@ -1177,7 +1177,7 @@ __device__ __forceinline__ Shaded shade_vertex(const DevScene& S, const float4* 
   // XZRect::random, hitable.rs:256-264
   F3 dir_light = f3(fmaf(xi1, S.light.f[1] - S.light.f[0], S.light.f[0]) - sf.p.x, S.light.f[4] - sf.p.y,
                     fmaf(xi2, S.light.f[3] - S.light.f[2], S.light.f[2]) - sf.p.z);
-  if (GENERAL != 0 && S.light_general) {
+  if (GENERAL == 3 && S.light_general) {
     // HitablePDF over a list of shapes: random() picks one uniformly; counter (pixel, sample, depth, 8192), word 0
     rt_light lt = S.light;
     if (S.n_lights > 1) {
@@ -1212,7 +1212,7 @@ __device__ __forceinline__ Shaded shade_vertex(const DevScene& S, const float4* 
     const float area = (S.light.f[1] - S.light.f[0]) * (S.light.f[3] - S.light.f[2]);
     const float cosine = fabsf(dir.y * inv_len);
     float lp = miss ? 0.0f : (t * t * dlen2) * fast_rcp(cosine * area);
-    if (GENERAL != 0 && S.light_general) {
+    if (GENERAL == 3 && S.light_general) {
       // pdf_value() of the list: the mean of the shapes' (a wave-uniform loop: the records arrive by scalar load)
       lp = 0.0f;
       for (int k = 0; k < S.n_lights; ++k) {
@@ -1331,9 +1331,10 @@ struct RenderArgs {
 // ---------------------------------------------------------------------------
 // GENERAL = 0 is the build for scenes made of Lambertian and DiffuseLight
 // surfaces with constant textures and no media (the Cornell box); 1 adds Metal,
-// Dielectric, Isotropic and ConstantMedium; 2 adds checker and noise textures.
+// Dielectric, Isotropic and ConstantMedium; 2 adds checker and noise textures; 3
+// adds light shapes other than one XZRect (lists of shapes, XY/YZ rects, spheres).
 template <bool STATS, bool SUMSQ, int TRAV, int GENERAL>
-__global__ void __launch_bounds__(64, (TRAV == TRAV_STACK && GENERAL != 2) ? 6 : ((GENERAL != 0 || TRAV == TRAV_STACK) ? 5 : RT_RENDER_WAVES_PER_SIMD)) render_kernel(DevScene S, DevCamera cam, RenderArgs A, float* __restrict__ out_sum,
+__global__ void __launch_bounds__(64, (TRAV == TRAV_STACK && GENERAL < 2) ? 6 : ((GENERAL != 0 || TRAV == TRAV_STACK) ? 5 : RT_RENDER_WAVES_PER_SIMD)) render_kernel(DevScene S, DevCamera cam, RenderArgs A, float* __restrict__ out_sum,
                                                      float* __restrict__ out_sumsq, unsigned long long* __restrict__ stats, unsigned* __restrict__ queue) {
   // Single-wave workgroups: every wave is on its own, none waits for the slowest
   // wave of a larger group.
@@ -1436,10 +1437,10 @@ __global__ void __launch_bounds__(64, (TRAV == TRAV_STACK && GENERAL != 2) ? 6 :
   int pix = 0;            // pixel within the tile
   unsigned pixel_id = 0;  // j*nx + i
   unsigned sample = 0;
-  int pend = -1;          // GENERAL == 2: a colour still to come from Texture::value, material index << 1 | ended-on-a-light
+  int pend = -1;          // GENERAL >= 2: a colour still to come from Texture::value, material index << 1 | ended-on-a-light
 
   for (;;) {
-    if (GENERAL == 2 && S.textured) {
+    if (GENERAL >= 2 && S.textured) {
       // ---- Texture::value of the previous vertex (texture.rs:22-35).  It is evaluated here, where only the path
       // state is live, instead of in the middle of the shading code: Perlin turbulence is a call, and everything live
       // across a call has to sit in the registers the callee preserves.  The vertex used colour (1,1,1); a path that
@@ -1574,7 +1575,7 @@ __global__ void __launch_bounds__(64, (TRAV == TRAV_STACK && GENERAL != 2) ? 6 :
     // the direction is kept clean (it feeds the reciprocals' range test meanwhile).
     ro = sh.p;
     rd = sel3(go_on, dir, rd);
-    if (GENERAL == 2) {
+    if (GENERAL >= 2) {
       const bool lit = textured & emits;  // its sample is thr * colour: the weight is kept for the top of the next trip
       pend = (textured & (go_on | emits)) ? (sh.mat_index << 1) | (lit ? 1 : 0) : -1;
       thr = sel3(lit, thr, thr_next);
@@ -1634,6 +1635,9 @@ __global__ void __launch_bounds__(64, (TRAV == TRAV_STACK && GENERAL != 2) ? 6 :
 #ifndef RT_SLOTS
 #define RT_SLOTS 2
 #endif
+#ifndef RT_STACK_WAVES
+#define RT_STACK_WAVES 5  // waves per SIMD the register allocator leaves room for in the builds without textures
+#endif
 // Diagnostic build (-DRT_PHASE_TIMING): shader-clock stamps around the parts of the loop, summed per wave into
 // stats[16..31] by the counting build and printed by rt_render.  No stamp exists in the normal build.
 #ifdef RT_PHASE_TIMING
@@ -1644,7 +1648,7 @@ __global__ void __launch_bounds__(64, (TRAV == TRAV_STACK && GENERAL != 2) ? 6 :
 #define RT_COUNT(k, v) do { } while (0)
 #endif
 template <bool STATS, bool SUMSQ, int GENERAL>
-__global__ void __launch_bounds__(64, GENERAL != 2 ? 6 : 5) render_stack_kernel(DevScene S, DevCamera cam, RenderArgs A, float* __restrict__ out_sum,
+__global__ void __launch_bounds__(64, GENERAL < 2 ? RT_STACK_WAVES : 5) render_stack_kernel(DevScene S, DevCamera cam, RenderArgs A, float* __restrict__ out_sum,
                                                      float* __restrict__ out_sumsq, unsigned long long* __restrict__ stats, unsigned* __restrict__ queue) {
   // Up to RT_SLOTS work items are open per wave: the one lanes take new paths from (slot f) and earlier ones whose
   // pools are empty and whose last paths are still on their way.  Paths reach depth 50 in scenes with media, and a
@@ -1713,7 +1717,7 @@ __global__ void __launch_bounds__(64, GENERAL != 2 ? 6 : 5) render_stack_kernel(
   for (;;) {
     // ======================= work items (wave-uniform) =======================
     {
-      const bool busy = alive | (GENERAL == 2 && pend >= 0);
+      const bool busy = alive | (GENERAL >= 2 && pend >= 0);
       if (fill_open && pool_next >= pool_size) fill_open = false;  // slot f goes on as a draining slot
       unsigned draining = open_mask & ~(fill_open ? (1u << f) : 0u);
       while (draining != 0u) {
@@ -1788,7 +1792,7 @@ __global__ void __launch_bounds__(64, GENERAL != 2 ? 6 : 5) render_stack_kernel(
 
     // ======================= shading phase: the lanes that are not in a traversal =======================
     const bool ready = !trav;
-    if (GENERAL == 2 && S.textured) {
+    if (GENERAL >= 2 && S.textured) {
       // Texture::value of the vertex before (see render_kernel): evaluated where little else is live.
       if (__ballot(ready & (pend >= 0)) != 0ull) {
         if (ready & (pend >= 0)) {
@@ -1848,7 +1852,7 @@ __global__ void __launch_bounds__(64, GENERAL != 2 ? 6 : 5) render_stack_kernel(
       }
       ro = sel3(act, sh.p, ro);
       rd = sel3(go_on, sh.dir, rd);
-      if (GENERAL == 2) {
+      if (GENERAL >= 2) {
         const bool lit = sh.textured & sh.emits;
         pend = act ? ((sh.textured & (go_on | sh.emits)) ? (sh.mat_index << 1) | (lit ? 1 : 0) : -1) : pend;
         thr = sel3(act, sel3(lit, thr, sh.thr_next), thr);
@@ -1860,7 +1864,7 @@ __global__ void __launch_bounds__(64, GENERAL != 2 ? 6 : 5) render_stack_kernel(
     }
     RT_STAMP(3);  // deposit + state update
     // A path that ended on a textured light keeps its lane until the colour has been added (top of the next shading phase).
-    const bool free_lane = ready & !alive & !(GENERAL == 2 && pend >= 0);
+    const bool free_lane = ready & !alive & !(GENERAL >= 2 && pend >= 0);
     // ---- hand (pixel, sample) items to the free lanes (main.rs:96-101) ----
     bool fresh = false;
     const unsigned long long need = __ballot(free_lane);
@@ -2048,7 +2052,7 @@ static __device__ __align__(256) unsigned char scratch[RT_NOALLOC_SCRATCH_BYTES]
 struct rt_ctx {
   int device;
   bool has_scene;
-  int general;  // build of the render kernel the scene needs: 0 Lambertian and lights only, 1 every material and media, 2 also textures
+  int general;  // build of the render kernel the scene needs: 0 Lambertian and lights only, 1 every material and media, 2 also textures, 3 also general light shapes
   DevScene dev;
   void* d_scan;
   void* d_prims;
@@ -2631,18 +2635,18 @@ int launch_render(rt_ctx* ctx, const rt_camera* cam, const rt_render_params* p, 
   const int n_items = n_tiles * A.n_chunks;
   const dim3 block(64);
   typedef void (*RenderFn)(DevScene, DevCamera, RenderArgs, float*, float*, unsigned long long*, unsigned*);
-#define RT_TRIO(ST, SQ, TR) render_kernel<ST, SQ, TR, 0>, render_kernel<ST, SQ, TR, 1>, render_kernel<ST, SQ, TR, 2>
-#define RT_ROW(ST, SQ) RT_TRIO(ST, SQ, TRAV_SCAN), RT_TRIO(ST, SQ, TRAV_FLAT), nullptr, nullptr, nullptr  /* stack scenes: render_stack_kernel */
-  static const RenderFn table[36] = {RT_ROW(false, false), RT_ROW(false, true), RT_ROW(true, false), RT_ROW(true, true)};
+#define RT_TRIO(ST, SQ, TR) render_kernel<ST, SQ, TR, 0>, render_kernel<ST, SQ, TR, 1>, render_kernel<ST, SQ, TR, 2>, render_kernel<ST, SQ, TR, 3>
+#define RT_ROW(ST, SQ) RT_TRIO(ST, SQ, TRAV_SCAN), RT_TRIO(ST, SQ, TRAV_FLAT), nullptr, nullptr, nullptr, nullptr  /* stack scenes: render_stack_kernel */
+  static const RenderFn table[48] = {RT_ROW(false, false), RT_ROW(false, true), RT_ROW(true, false), RT_ROW(true, true)};
 #undef RT_ROW
 #undef RT_TRIO
   const int trav = ctx->dev.stack_mode ? TRAV_STACK : (ctx->dev.flat ? TRAV_FLAT : TRAV_SCAN);
-#define RT_STK(ST, SQ) render_stack_kernel<ST, SQ, 0>, render_stack_kernel<ST, SQ, 1>, render_stack_kernel<ST, SQ, 2>
-  static const RenderFn stack_table[12] = {RT_STK(false, false), RT_STK(false, true), RT_STK(true, false), RT_STK(true, true)};
+#define RT_STK(ST, SQ) render_stack_kernel<ST, SQ, 0>, render_stack_kernel<ST, SQ, 1>, render_stack_kernel<ST, SQ, 2>, render_stack_kernel<ST, SQ, 3>
+  static const RenderFn stack_table[16] = {RT_STK(false, false), RT_STK(false, true), RT_STK(true, false), RT_STK(true, true)};
 #undef RT_STK
-  RenderFn fn = table[(stats ? 18 : 0) + (d_sumsq ? 9 : 0) + trav * 3 + ctx->general];
+  RenderFn fn = table[(stats ? 24 : 0) + (d_sumsq ? 12 : 0) + trav * 4 + ctx->general];
   // scenes on the per-lane stack traversal: the kernel that keeps a lane's traversal going across the shading code
-  if (trav == TRAV_STACK) fn = stack_table[(stats ? 6 : 0) + (d_sumsq ? 3 : 0) + ctx->general];
+  if (trav == TRAV_STACK) fn = stack_table[(stats ? 8 : 0) + (d_sumsq ? 4 : 0) + ctx->general];
   size_t lds_bytes = trav == TRAV_FLAT ? (size_t)ctx->dev.n_dprims * 6 * sizeof(float4) : 0;
   if (trav == TRAV_STACK) lds_bytes = (size_t)ctx->dev.stack_lds * 64 * sizeof(unsigned);
 
@@ -2913,8 +2917,8 @@ int rt_upload_scene(rt_ctx* ctx, const rt_scene* s) {
   if ((rc = upload(&ctx->d_lights, s->lights, (size_t)s->n_lights)) != RT_OK) return rc;
   d.lights = (const rt_light*)ctx->d_lights;
   d.light_general = (s->n_lights > 1 || (s->n_lights == 1 && s->lights[0].type != RT_LIGHT_XZ_RECT)) ? 1 : 0;
-  // (the general light code is compiled into the builds 1 and 2 only, so that the Cornell build keeps its registers)
-  ctx->general = textured ? 2 : d.light_general ? 1 : ((!B.media.empty() || (mat_mask & ~((1 << RT_MAT_LAMBERTIAN) | (1 << RT_MAT_DIFFUSE_LIGHT))) != 0) ? 1 : 0);
+  // (the general light code is compiled into build 3 only, so that the other builds keep their registers)
+  ctx->general = d.light_general ? 3 : textured ? 2 : ((!B.media.empty() || (mat_mask & ~((1 << RT_MAT_LAMBERTIAN) | (1 << RT_MAT_DIFFUSE_LIGHT))) != 0) ? 1 : 0);
   ctx->has_scene = true;
   return RT_OK;
 }
