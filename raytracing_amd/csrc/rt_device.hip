@@ -146,9 +146,9 @@ struct BNode {
 };
 #define BN_INDEX_MASK 0x0fffffff
 // What the stack traversal fetches at an interior node, 128 bytes (one cache line): the boxes of up to four
-// descendants and where they are.  The binary tree of bvh.rs is collapsed two levels at a time on upload: a
-// node's entry holds its grandchildren (or a child itself where that child is a leaf).  Leaving out the box test
-// of the child in between changes no result: a box lies inside its parent's and the slab arithmetic is monotonic
+// descendants and where they are.  The binary tree of bvh.rs is collapsed on upload: a node's entry holds up to four
+// of its descendants (its two children, the larger interior ones opened into their own children while there is
+// room).  Leaving out the box test of a node in between changes no result: a box lies inside its parent's and the slab arithmetic is monotonic
 // in the bounds, so a ray that passes a node's Aabb::hit passes every ancestor's.  Half as many dependent
 // fetches per ray, each deciding four box tests.  A reference is an index into this array for an interior
 // descendant, the descendant's index in the breadth-first array with BN2_LEAF set for a leaf, and for a leaf of
@@ -773,7 +773,7 @@ __device__ __forceinline__ bool trav_step(const DevScene& S, LaneStack& stk, Tra
   const bool h2 = slab_core(lox.z, loy.z, loz.z, hix.z, hiy.z, hiz.z, top.z, T.r, sg, t_min, t_max, T.best.t, t2);
   const bool h3 = slab_core(lox.w, loy.w, loz.w, hix.w, hiy.w, hiz.w, top.w, T.r, sg, t_min, t_max, T.best.t, t3);
   const int r0 = __float_as_int(refs_f.x), r1 = __float_as_int(refs_f.y), r2 = __float_as_int(refs_f.z), r3 = __float_as_int(refs_f.w);
-  if (STATS) cnt.node_tests += 2u + (r2 != BN4_EMPTY) + (r3 != BN4_EMPTY);
+  if (STATS) cnt.node_tests += 2u + (r2 != BN4_EMPTY) + (r3 != BN4_EMPTY);  // (empty slots are the last ones)
   // Order by entry distance: the distance (not negative, so its bits order like an integer) with its two lowest bits
   // replaced by the slot number is one sortable key per descendant; a miss sorts last.  Which of two equally near
   // boxes comes first does not matter: the winner is decided by t and, on an exact tie, by leaf rank.
@@ -2443,40 +2443,191 @@ int build_bnodes(const rt_scene* s, int idx, std::vector<BNode>* out, std::vecto
   return RT_OK;
 }
 
-// The four-wide view of the tree under the interior node `idx` (see BNode4): its entry holds the node's
-// grandchildren, or a child itself where that child is a leaf.  Returns the entry's index in `out`.  `need` receives
-// the stack entries a lane can have in use below this entry: while it is inside one descendant the others it entered
-// wait on the stack, and an object's sub-tree adds its marker.
-struct Wide4Builder {
+// The tree the stack traversal walks.  Its LEAVES are the reference tree's leaves with the reference's boxes, and the
+// order that decides an exact tie is the reference's depth-first order (prim_rank); its interior structure is the
+// device's own.  That changes no result: BvhNode::hit (bvh.rs:197-228) returns the nearest hit among the leaves that
+// the ray reaches, a ray reaches a leaf exactly when it passes the box of every node on the way down, every such box
+// contains the leaf's own box and the slab arithmetic is monotonic in the bounds, so "reaches the leaf" is "passes
+// the leaf's own box" whatever lies above it.  The reference's interior (a random axis per node, median split,
+// bvh.rs:105-147) makes a poor tree to walk; this one is built top-down with the surface area heuristic over 16
+// bins per axis, and its interior boxes are the exact unions of the leaf boxes below them.
+struct BuildNode {
+  float bmin[3], bmax[3];
+  float top;     // y_top (see slab_core)
+  int left, right;
+  int ref_node;  // a leaf: the reference node it stands for; -1 for an interior node
+};
+
+struct TreeBuilder {
   const rt_scene* s;
   const std::vector<float>* y_top;
+  std::vector<BuildNode> nodes;
+  bool halve_only;  // no heuristic: halve every range as it stands (a balanced tree; the fallback when the other one is too deep)
+
+  // the reference leaves under reference node idx, in the reference's depth-first order (objects are leaves here)
+  void collect(int idx, std::vector<int>* out) const {
+    const rt_node& n = s->nodes[idx];
+    if (n.left < 0) { out->push_back(idx); return; }
+    collect(n.left, out);
+    collect(n.right, out);
+  }
+  int make_leaf(int ref) {
+    const rt_node& n = s->nodes[ref];
+    BuildNode b;
+    for (int c = 0; c < 3; ++c) { b.bmin[c] = n.bmin[c]; b.bmax[c] = n.bmax[c]; }
+    b.top = (*y_top)[(size_t)ref];
+    b.left = b.right = -1;
+    b.ref_node = ref;
+    nodes.push_back(b);
+    return (int)nodes.size() - 1;
+  }
+  static double half_area(const float* lo, const float* hi) {
+    const double dx = (double)hi[0] - lo[0], dy = (double)hi[1] - lo[1], dz = (double)hi[2] - lo[2];
+    return dx * dy + dy * dz + dz * dx;
+  }
+  // builds the subtree over leaves[begin, end) (reference node indices; reordered in place); returns its node
+  int build(std::vector<int>& leaves, int begin, int end, int depth = 0) {
+    if (end - begin == 1) return make_leaf(leaves[(size_t)begin]);
+    const int kBins = 16;
+    const bool halve = halve_only || depth > 40;  // (a heuristic split can peel off one leaf at a time: bounded here)
+    float cmin[3] = {INFINITY, INFINITY, INFINITY}, cmax[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int i = begin; i < end; ++i) {
+      const rt_node& n = s->nodes[leaves[(size_t)i]];
+      for (int c = 0; c < 3; ++c) {
+        const float ctr = 0.5f * n.bmin[c] + 0.5f * n.bmax[c];
+        if (ctr < cmin[c]) cmin[c] = ctr;
+        if (ctr > cmax[c]) cmax[c] = ctr;
+      }
+    }
+    int best_axis = -1, best_split = 0;
+    double best_cost = INFINITY;
+    for (int axis = 0; axis < 3 && !halve; ++axis) {
+      const float extent = cmax[axis] - cmin[axis];
+      if (!(extent > 0.0f) || !std::isfinite(extent)) continue;
+      float blo[kBins][3], bhi[kBins][3];
+      int cnt[kBins];
+      for (int k = 0; k < kBins; ++k) {
+        cnt[k] = 0;
+        for (int c = 0; c < 3; ++c) { blo[k][c] = INFINITY; bhi[k][c] = -INFINITY; }
+      }
+      const float scale = (float)kBins / extent;
+      for (int i = begin; i < end; ++i) {
+        const rt_node& n = s->nodes[leaves[(size_t)i]];
+        int k = (int)((0.5f * n.bmin[axis] + 0.5f * n.bmax[axis] - cmin[axis]) * scale);
+        k = k < 0 ? 0 : (k >= kBins ? kBins - 1 : k);
+        ++cnt[k];
+        for (int c = 0; c < 3; ++c) {
+          if (n.bmin[c] < blo[k][c]) blo[k][c] = n.bmin[c];
+          if (n.bmax[c] > bhi[k][c]) bhi[k][c] = n.bmax[c];
+        }
+      }
+      // sweep from the right, then from the left
+      double right_area[kBins];
+      int right_cnt[kBins];
+      float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+      int c_acc = 0;
+      for (int k = kBins - 1; k > 0; --k) {
+        c_acc += cnt[k];
+        for (int c = 0; c < 3; ++c) { if (blo[k][c] < lo[c]) lo[c] = blo[k][c]; if (bhi[k][c] > hi[c]) hi[c] = bhi[k][c]; }
+        right_cnt[k] = c_acc;
+        right_area[k] = c_acc ? half_area(lo, hi) : 0.0;
+      }
+      for (int c = 0; c < 3; ++c) { lo[c] = INFINITY; hi[c] = -INFINITY; }
+      c_acc = 0;
+      for (int k = 0; k < kBins - 1; ++k) {
+        c_acc += cnt[k];
+        for (int c = 0; c < 3; ++c) { if (blo[k][c] < lo[c]) lo[c] = blo[k][c]; if (bhi[k][c] > hi[c]) hi[c] = bhi[k][c]; }
+        if (c_acc == 0 || right_cnt[k + 1] == 0) continue;
+        double cost = half_area(lo, hi) * c_acc + right_area[k + 1] * right_cnt[k + 1];
+        if (!(cost == cost)) cost = INFINITY;  // a box with an infinite side
+        if (cost < best_cost) { best_cost = cost; best_axis = axis; best_split = k + 1; }
+      }
+    }
+    int mid = begin + (end - begin) / 2;
+    if (best_axis >= 0) {
+      const float scale = (float)kBins / (cmax[best_axis] - cmin[best_axis]);
+      const float base = cmin[best_axis];
+      const int axis = best_axis, split = best_split;
+      auto bin_of = [&](int ref) {
+        const rt_node& n = s->nodes[ref];
+        int k = (int)((0.5f * n.bmin[axis] + 0.5f * n.bmax[axis] - base) * scale);
+        return k < 0 ? 0 : (k >= kBins ? kBins - 1 : k);
+      };
+      int* first = leaves.data() + begin;
+      int* last = leaves.data() + end;
+      int* m = std::stable_partition(first, last, [&](int ref) { return bin_of(ref) < split; });
+      mid = (int)(m - leaves.data());
+      if (mid == begin || mid == end) mid = begin + (end - begin) / 2;
+    }
+    // (all centres in one point, or nothing to gain: halve the range as it stands)
+    const int l = build(leaves, begin, mid, depth + 1);
+    const int r = build(leaves, mid, end, depth + 1);
+    BuildNode b;
+    for (int c = 0; c < 3; ++c) {
+      b.bmin[c] = nodes[(size_t)l].bmin[c] < nodes[(size_t)r].bmin[c] ? nodes[(size_t)l].bmin[c] : nodes[(size_t)r].bmin[c];
+      b.bmax[c] = nodes[(size_t)l].bmax[c] > nodes[(size_t)r].bmax[c] ? nodes[(size_t)l].bmax[c] : nodes[(size_t)r].bmax[c];
+    }
+    b.top = nodes[(size_t)l].top > nodes[(size_t)r].top ? nodes[(size_t)l].top : nodes[(size_t)r].top;
+    b.left = l;
+    b.right = r;
+    b.ref_node = -1;
+    nodes.push_back(b);
+    return (int)nodes.size() - 1;
+  }
+  // the device's tree over the reference leaves under reference node idx
+  int build_under(int idx) {
+    std::vector<int> leaves;
+    collect(idx, &leaves);
+    return build(leaves, 0, (int)leaves.size());
+  }
+};
+
+// The four-wide view of a built tree (see BNode4): an entry holds up to four descendants of its node.  `need`
+// receives the stack entries a lane can have in use below an entry: while it is inside one descendant the others
+// it entered wait on the stack, and an object's sub-tree adds its marker.
+struct Wide4Builder {
+  const rt_scene* s;
+  TreeBuilder* T;
   std::vector<BNode4> out;
   std::vector<int> sub_root_ref;  // per object
-  int ref_of_leaf(int child) const {
-    const rt_node& c = s->nodes[child];
-    return c.right == 1 ? (BN2_LEAF | BN2_PRIM | ~c.left) : (BN2_LEAF | child);
+  int ref_of_leaf(int ref_node) const {
+    const rt_node& c = s->nodes[ref_node];
+    return c.right == 1 ? (BN2_LEAF | BN2_PRIM | ~c.left) : (BN2_LEAF | ref_node);
   }
-  // the reference of node `idx` (interior: builds its entry) and the stack it needs
+  // the reference of built node `idx` (interior: builds its entry) and the stack it needs
   int ref_of(int idx, int* need) {
-    const rt_node& n = s->nodes[idx];
-    if (n.left >= 0) return build(idx, need);
+    const BuildNode n = T->nodes[(size_t)idx];
+    if (n.ref_node < 0) return build(idx, need);
     *need = 0;
-    if (n.right == 0 && s->objects[~n.left].kind == RT_OBJ_BVH) {
+    const rt_node& leaf = s->nodes[n.ref_node];
+    if (leaf.right == 0 && s->objects[~leaf.left].kind == RT_OBJ_BVH) {
       int sub = 0;
-      const int r = ref_of(s->objects[~n.left].first, &sub);
-      sub_root_ref[(size_t)~n.left] = r;
+      const int sub_root = T->build_under(s->objects[~leaf.left].first);
+      const int r = ref_of(sub_root, &sub);
+      sub_root_ref[(size_t)~leaf.left] = r;
       *need = 1 + sub;  // the marker that switches the lane back to the outer frame
     }
-    return ref_of_leaf(idx);
+    return ref_of_leaf(n.ref_node);
   }
   int build(int idx, int* need) {
-    const rt_node& n = s->nodes[idx];
-    int kids[4], n_kids = 0;
-    const int two[2] = {n.left, n.right};
-    for (int c = 0; c < 2; ++c) {
-      const rt_node& ch = s->nodes[two[c]];
-      if (ch.left >= 0) { kids[n_kids++] = ch.left; kids[n_kids++] = ch.right; }
-      else kids[n_kids++] = two[c];
+    // Start from the two children and, while there is room, open the interior one with the largest box (the one a
+    // ray is most likely to enter anyway) into its own two children, keeping the left-to-right order.
+    int kids[4] = {T->nodes[(size_t)idx].left, T->nodes[(size_t)idx].right, 0, 0}, n_kids = 2;
+    while (n_kids < 4) {
+      int pick = -1;
+      double pick_area = -1.0;
+      for (int c = 0; c < n_kids; ++c) {
+        const BuildNode& k = T->nodes[(size_t)kids[c]];
+        if (k.ref_node >= 0) continue;
+        const double area = TreeBuilder::half_area(k.bmin, k.bmax);
+        if (area > pick_area || pick < 0) { pick_area = area; pick = c; }
+      }
+      if (pick < 0) break;
+      const BuildNode k = T->nodes[(size_t)kids[pick]];
+      for (int c = n_kids; c > pick + 1; --c) kids[c] = kids[c - 1];
+      kids[pick + 1] = k.right;
+      kids[pick] = k.left;
+      ++n_kids;
     }
     const int at = (int)out.size();
     out.push_back(BNode4());
@@ -2484,10 +2635,10 @@ struct Wide4Builder {
     int deepest = 0;
     for (int c = 0; c < 4; ++c) {
       if (c < n_kids) {
-        const rt_node& k = s->nodes[kids[c]];
+        const BuildNode k = T->nodes[(size_t)kids[c]];
         b.lox[c] = k.bmin[0]; b.loy[c] = k.bmin[1]; b.loz[c] = k.bmin[2];
         b.hix[c] = k.bmax[0]; b.hiy[c] = k.bmax[1]; b.hiz[c] = k.bmax[2];
-        b.top[c] = (*y_top)[(size_t)kids[c]];
+        b.top[c] = k.top;
         int sub = 0;
         b.ref[c] = ref_of(kids[c], &sub);
         if (sub > deepest) deepest = sub;
@@ -2777,15 +2928,26 @@ int rt_upload_scene(rt_ctx* ctx, const rt_scene* s) {
   const int depth = tree_depth(s, 0);
   const bool want_stack = B.any_interior && depth <= STACK_DEPTH - 2;
   // the four-wide entries of the interior nodes, and the six-rect records of the list leaves
+  TreeBuilder TB;
+  TB.s = s;
+  TB.y_top = &B.y_top;
+  TB.halve_only = false;
   Wide4Builder W;
   W.s = s;
-  W.y_top = &B.y_top;
+  W.T = &TB;
   W.sub_root_ref.assign((size_t)s->n_objects, 0);
   int root_ref = 0, stack_need = 0;
   std::vector<int> box6_index((size_t)s->n_prims, -1);
   std::vector<float> box6_recs;
   if (want_stack) {
-    root_ref = W.ref_of(0, &stack_need);
+    root_ref = W.ref_of(TB.build_under(0), &stack_need);
+    if (stack_need + 2 > RT_STACK_LDS + RT_STACK_PRIVATE) {
+      // the heuristic's tree is too deep for a lane's stack: the balanced one over the same leaves
+      TB.nodes.clear();
+      TB.halve_only = true;
+      W.out.clear();
+      root_ref = W.ref_of(TB.build_under(0), &stack_need);
+    }
     if (W.out.size() > (size_t)BN_INDEX_MASK) return rt::set_error(RT_ERR_UNSUPPORTED, "too many nodes");
     auto note_box6 = [&](int first, int count) {
       if (!box6_flag(s, first, count)) return;
