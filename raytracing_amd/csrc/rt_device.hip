@@ -2465,9 +2465,15 @@ struct TreeBuilder {
   bool halve_only;  // no heuristic: halve every range as it stands (a balanced tree; the fallback when the other one is too deep)
 
   // the reference leaves under reference node idx, in the reference's depth-first order (objects are leaves here)
+  // A BvhNode used as an item without Translate or RotateY lives in its parent's frame: its leaves join the parent's
+  // tree (the same argument: a leaf of it is reached exactly when the ray passes that leaf's own box).
   void collect(int idx, std::vector<int>* out) const {
     const rt_node& n = s->nodes[idx];
-    if (n.left < 0) { out->push_back(idx); return; }
+    if (n.left < 0) {
+      if (n.right == 0 && s->objects[~n.left].kind == RT_OBJ_BVH && (s->objects[~n.left].xform & 3) == 0) collect(s->objects[~n.left].first, out);
+      else out->push_back(idx);
+      return;
+    }
     collect(n.left, out);
     collect(n.right, out);
   }
@@ -3063,6 +3069,10 @@ int rt_upload_scene(rt_ctx* ctx, const rt_scene* s) {
   d.stack_mode = stack_mode ? 1 : 0;
   d.stack_depth = stack_mode ? stack_need + 2 : 0;  // what the deepest walk can have in use, and a margin
   d.stack_lds = d.stack_depth < RT_STACK_LDS ? d.stack_depth : RT_STACK_LDS;
+  if (getenv("RT_VERBOSE"))
+    std::fprintf(stderr, "rt_upload_scene: %d nodes, %d primitives, reference tree depth %d; traversal %s; four-wide entries %zu, stack entries per lane %d (%s tree)\n",
+                 s->n_nodes, s->n_prims, depth, stack_mode ? "stack" : (d.flat ? "flat" : "scan"), W.out.size(), d.stack_depth,
+                 TB.halve_only ? "balanced" : "surface-area");
   d.mat_mask = mat_mask;
   d.textured = textured;
   d.has_spheres = 0;
