@@ -419,17 +419,22 @@ __device__ __forceinline__ bool rect_test(const float* f, const RayF& r, float t
 // ray and t within 1e-5 relative on 99.98 % of them.  A negative h makes the
 // square root, and with it every comparison, fail on its own; h == 0 is excluded
 // as discriminant == 0 is in the source.
-__device__ __forceinline__ bool sphere_test(const float* f, const RayF& r, float t_min, float t_max, float& t_out) {
+// h (the discriminant's sign) and the two roots; the roots are NaN when h < 0.
+__device__ __forceinline__ void sphere_roots(const float* f, const RayF& r, float& h, float& t_near, float& t_far) {
   const F3 oc = f3(r.o.x - f[0], r.o.y - f[1], r.o.z - f[2]);
   const float a = dot3(r.d, r.d);
   const float b = dot3(oc, r.d);
   const float inv_a = exact_rcp(a);
   const float k = b * inv_a;
   const F3 l = f3(fmaf(-k, r.d.x, oc.x), fmaf(-k, r.d.y, oc.y), fmaf(-k, r.d.z, oc.z));
-  const float h = fmaf(f[3], f[3], -dot3(l, l));
+  h = fmaf(f[3], f[3], -dot3(l, l));
   const float sq = sqrtf(h * inv_a);
-  const float t_near = -k - sq;
-  const float t_far = -k + sq;
+  t_near = -k - sq;
+  t_far = -k + sq;
+}
+__device__ __forceinline__ bool sphere_test(const float* f, const RayF& r, float t_min, float t_max, float& t_out) {
+  float h, t_near, t_far;
+  sphere_roots(f, r, h, t_near, t_far);
   const bool near_ok = (t_near < t_max) & (t_near > t_min);
   const bool far_ok = (t_far < t_max) & (t_far > t_min);
   t_out = near_ok ? t_near : t_far;
@@ -593,34 +598,61 @@ __device__ __forceinline__ void scan_range(const DevScene& S, int begin, int end
         const ScanNode ext = load_node(S.scan, n.skip - 1);  // density, ordinal, DevPrim index
         Hit b1, b2;
         b1.t = 3.402823466e+38f; b1.prim = -1;
-        if (box6) box6_test<STATS>(S.scan, i, n.a, on, q, -3.402823466e+38f, 3.402823466e+38f, b1, cnt);
-        else list_test<STATS>(S.prims, n.a, n.b & 0x7fffff, on, q, -3.402823466e+38f, 3.402823466e+38f, b1, cnt);
         b2.t = 3.402823466e+38f; b2.prim = -1;
-        // hitable.rs:566 searches on from rec1.t + 0.0001.  Not in the reference, which works in f64: beyond t = 2048 that
-        // sum is rec1.t itself in fp32 and a rect (whose test accepts t == t_min) would be found again, so the search
-        // starts at the next float above rec1.t at least.
-        float t_next = b1.t + 0.0001f;
-        {
-          const int bits = __float_as_int(b1.t);
-          const float up = __int_as_float(bits >= 0 ? bits + 1 : (bits == (int)0x80000000 ? 1 : bits - 1));
-          t_next = t_next > b1.t ? t_next : up;
+        const int n_boundary = n.b & 0x7fffff;
+        const rt_prim bq = load_prim_uniform(S.prims, n.a);
+        if (!box6 && n_boundary == 1 && (bq.type & RT_PRIM_TYPE_MASK) == RT_PRIM_SPHERE) {
+          // A sphere as the boundary: the two searches below are the two roots of one quadratic, so it is solved once.
+          // Each search takes the nearer root inside its interval, else the farther one, exactly as Sphere::hit does.
+          float h, t_near, t_far;
+          sphere_roots(bq.f, q, h, t_near, t_far);
+          if (STATS) cnt.sphere_tests += on ? 2u : 0u;
+          const float big = 3.402823466e+38f;
+          const bool n1 = (t_near < big) & (t_near > -big), f1 = (t_far < big) & (t_far > -big);
+          const bool v1 = on & (h > 0.0f) & (n1 | f1);
+          b1.t = v1 ? (n1 ? t_near : t_far) : b1.t;
+          b1.prim = v1 ? n.a : -1;
+          float t_next = b1.t + 0.0001f;
+          {
+            const int bits = __float_as_int(b1.t);
+            const float up = __int_as_float(bits >= 0 ? bits + 1 : (bits == (int)0x80000000 ? 1 : bits - 1));
+            t_next = t_next > b1.t ? t_next : up;
+          }
+          const bool n2 = (t_near < big) & (t_near > t_next), f2 = (t_far < big) & (t_far > t_next);
+          const bool v2 = on & (h > 0.0f) & (n2 | f2);
+          b2.t = v2 ? (n2 ? t_near : t_far) : b2.t;
+          b2.prim = v2 ? n.a : -1;
+        } else {
+          if (box6) box6_test<STATS>(S.scan, i, n.a, on, q, -3.402823466e+38f, 3.402823466e+38f, b1, cnt);
+          else list_test<STATS>(S.prims, n.a, n_boundary, on, q, -3.402823466e+38f, 3.402823466e+38f, b1, cnt);
+          // hitable.rs:566 searches on from rec1.t + 0.0001.  Not in the reference, which works in f64: beyond t = 2048 that
+          // sum is rec1.t itself in fp32 and a rect (whose test accepts t == t_min) would be found again, so the search
+          // starts at the next float above rec1.t at least.
+          float t_next = b1.t + 0.0001f;
+          {
+            const int bits = __float_as_int(b1.t);
+            const float up = __int_as_float(bits >= 0 ? bits + 1 : (bits == (int)0x80000000 ? 1 : bits - 1));
+            t_next = t_next > b1.t ? t_next : up;
+          }
+          if (box6) box6_test<STATS>(S.scan, i, n.a, on, q, t_next, 3.402823466e+38f, b2, cnt);
+          else list_test<STATS>(S.prims, n.a, n_boundary, on, q, t_next, 3.402823466e+38f, b2, cnt);
         }
-        if (box6) box6_test<STATS>(S.scan, i, n.a, on, q, t_next, 3.402823466e+38f, b2, cnt);
-        else list_test<STATS>(S.prims, n.a, n.b & 0x7fffff, on, q, t_next, 3.402823466e+38f, b2, cnt);
         float t1 = b1.t, t2 = b2.t;
         t1 = t1 < t_min ? t_min : t1;
         t2 = t2 > t_max ? t_max : t2;
         bool ok = on & (b1.prim >= 0) & (b2.prim >= 0) & !(t1 >= t2);
-        t1 = t1 < 0.0f ? 0.0f : t1;
-        const float dlen = sqrtf(dot3(r.d, r.d));
-        const float inside = (t2 - t1) * dlen;
-        const U4 mw = philox4x32_10(rng.pixel, rng.sample, rng.depth, 4096u + (unsigned)ext.a, rng.key0, rng.key1);
-        const float hit_distance = -(1.0f / ext.f[0]) * __logf(u01(mw.x));
-        const float t = t1 + hit_distance / dlen;
-        ok &= (hit_distance < inside) & !(best.t < t);
-        best.t = ok ? t : best.t;
-        best.prim = ok ? ext.b : best.prim;
         if (STATS) cnt.instance_ops += on;
+        if (__ballot(ok) != 0ull) {  // the draw is only made where some ray crosses the medium
+          t1 = t1 < 0.0f ? 0.0f : t1;
+          const float dlen = sqrtf(dot3(r.d, r.d));
+          const float inside = (t2 - t1) * dlen;
+          const U4 mw = philox4x32_10(rng.pixel, rng.sample, rng.depth, 4096u + (unsigned)ext.a, rng.key0, rng.key1);
+          const float hit_distance = -(1.0f / ext.f[0]) * __logf(u01(mw.x));
+          const float t = t1 + hit_distance / dlen;
+          ok &= (hit_distance < inside) & !(best.t < t);
+          best.t = ok ? t : best.t;
+          best.prim = ok ? ext.b : best.prim;
+        }
       }
     }
     // A leaf's skip is the next node (past any extension slots); an interior node's first child follows it.
