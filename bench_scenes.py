@@ -264,10 +264,9 @@ def main():
     roofline = {"bound": "valu", "achieved": round(flops / (t_ms * 1e-3) / 1e12, 3), "peak": VALU_PEAK_TFLOPS * n_ranks, "unit": "TFLOP/s"}
     roofline["frac"] = round(roofline["achieved"] / roofline["peak"], 4)
     if args.scene == "stress":
-        bytes_ = 32.0 * node_tests + 20.0 * sphere_tests
-        gbs = bytes_ / (t_ms * 1e-3) / 1e9
-        roofline["memory"] = {"algorithmic_GB/s": round(gbs, 1), "peak": HBM_PEAK_GBS * n_ranks, "frac": round(gbs / (HBM_PEAK_GBS * n_ranks), 4),
-                              "note": "32 B per box test + 20 B per sphere test; measured fabric traffic is in profiles/"}
+        # request bytes are not traffic (nearly all are served by L1/L2): they are listed, not compared with a peak; the
+        # fabric traffic of this scene comes from the PMC profile (tools/profile_stress.sh, profiles/r2/stress_summary.txt)
+        roofline["request_bytes_per_launch"] = int(32.0 * node_tests + 20.0 * sphere_tests)
     line = {
         "scene": args.scene, "nx": args.nx, "ny": args.ny, "spp": args.spp, "nodes": flat.n_nodes, "prims": flat.n_prims,
         "tree": "device LBVH (variant)" if args.lbvh else "reference median split", "lbvh_build_s": None if t_lbvh is None else round(t_lbvh, 4),
