@@ -1350,6 +1350,7 @@ struct RenderArgs {
   int split_parts;          // the last of which is cut into this many parts, each half the one before
   int ready_lanes;          // render_stack_kernel: finished rays in a wave (in 64 live ones) that end a traversal phase
   int hold_lanes;           // and lanes holding a leaf (in 64 traversing ones) that make the wave run the leaf code
+  int accumulate;           // render_stack_kernel: items ADD their tile sums to the (zeroed) output instead of writing partial images
 };
 
 // Waves per SIMD the register allocator must leave room for (launch_bounds' second argument).
@@ -1667,6 +1668,9 @@ __global__ void __launch_bounds__(64, (TRAV == TRAV_STACK && GENERAL < 2) ? 6 : 
 #ifndef RT_SLOTS
 #define RT_SLOTS 2
 #endif
+#ifndef RT_STACK_LAST_SPP
+#define RT_STACK_LAST_SPP 4  // render_stack_kernel: the last sample chunk of a tile is halved down to parts of this many samples
+#endif
 #ifndef RT_STACK_WAVES
 #define RT_STACK_WAVES 5  // waves per SIMD the register allocator leaves room for in the builds without textures
 #endif
@@ -1747,81 +1751,6 @@ __global__ void __launch_bounds__(64, GENERAL < 2 ? RT_STACK_WAVES : 5) render_s
   T.best.prim = -1;
 
   for (;;) {
-    // ======================= work items (wave-uniform) =======================
-    {
-      const bool busy = alive | (GENERAL >= 2 && pend >= 0);
-      if (fill_open && pool_next >= pool_size) fill_open = false;  // slot f goes on as a draining slot
-      unsigned draining = open_mask & ~(fill_open ? (1u << f) : 0u);
-      while (draining != 0u) {
-        const int d = __builtin_ctz(draining);
-        draining &= draining - 1u;
-        if (__ballot(busy & ((pix >> 6) == d)) != 0ull) continue;
-        // the last path of this item has ended: write its tile (main.rs:112-114; sums, not means)
-        const int dtx = slot_info[d][0], dty = slot_info[d][1], chunk = slot_info[d][2];
-        const size_t slab = (size_t)chunk * A.nx * A.ny * 3;
-        const int px = dtx * 8 + (lane & 7);
-        const int row = dty * 8 + (lane >> 3);
-        if (px < A.nx && row < A.ny) {
-          const size_t at = slab + ((size_t)row * A.nx + px) * 3;
-          out_sum[at] = acc[0][d * 64 + lane];
-          out_sum[at + 1] = acc[1][d * 64 + lane];
-          out_sum[at + 2] = acc[2][d * 64 + lane];
-          if (SUMSQ) {
-            out_sumsq[at] = acc[3][d * 64 + lane];
-            out_sumsq[at + 1] = acc[4][d * 64 + lane];
-            out_sumsq[at + 2] = acc[5][d * 64 + lane];
-          }
-        }
-        open_mask &= ~(1u << d);
-      }
-      if (!fill_open && !queue_empty && open_mask != (1u << RT_SLOTS) - 1u) {
-        int item = 0;
-        if (lane == 0) item = (int)atomicAdd(queue, 1u);
-        item = __builtin_amdgcn_readfirstlane(item);
-        if (item >= n_items) {
-          queue_empty = true;
-        } else {
-          f = __builtin_ctz(~open_mask);
-          const int chunk = item / n_tiles;
-          const int tile = item - chunk * n_tiles;
-          tx = tile % A.tiles_x;
-          ty = tile / A.tiles_x;
-          bool mine = true;
-          if (A.shard_count > 1) {
-            const int blocks_x = (A.nx + 63) / 64;
-            const int block = A.shard_index + (tile >> 6) * A.shard_count;
-            tx = (block % blocks_x) * 8 + (tile & 7);
-            ty = (block / blocks_x) * 8 + ((tile >> 3) & 7);
-            mine = (tx < A.tiles_x) & (ty < A.tiles_y);
-          }
-#pragma unroll
-          for (int c = 0; c < (SUMSQ ? 6 : 3); ++c) acc[c][f * 64 + lane] = 0.0f;
-          if (lane == 0) {
-            slot_info[f][0] = tx;
-            slot_info[f][1] = ty;
-            slot_info[f][2] = chunk;
-          }
-          // the last chunk comes in halving parts (see render_kernel)
-          const int n_whole = A.n_chunks - A.split_parts;
-          int s_len = A.chunk_spp;
-          s_first = chunk * A.chunk_spp;
-          if (chunk >= n_whole) {
-            const int k = chunk - n_whole;
-            const int last = A.spp - n_whole * A.chunk_spp;
-            const int o0 = last - (last >> k);
-            const int o1 = k + 1 < A.split_parts ? last - (last >> (k + 1)) : last;
-            s_first = n_whole * A.chunk_spp + o0;
-            s_len = o1 - o0;
-          }
-          pool_size = mine ? 64 * s_len : 0;
-          pool_next = 0;
-          open_mask |= 1u << f;
-          fill_open = true;
-        }
-      }
-      if (open_mask == 0u && queue_empty) break;
-    }
-
     // ======================= shading phase: the lanes that are not in a traversal =======================
     const bool ready = !trav;
     if (GENERAL >= 2 && S.textured) {
@@ -1895,36 +1824,132 @@ __global__ void __launch_bounds__(64, GENERAL < 2 ? RT_STACK_WAVES : 5) render_s
       alive = act ? go_on : alive;
     }
     RT_STAMP(3);  // deposit + state update
-    // A path that ended on a textured light keeps its lane until the colour has been added (top of the next shading phase).
-    const bool free_lane = ready & !alive & !(GENERAL >= 2 && pend >= 0);
-    // ---- hand (pixel, sample) items to the free lanes (main.rs:96-101) ----
-    bool fresh = false;
-    const unsigned long long need = __ballot(free_lane);
-    if (need != 0ull && fill_open && pool_next < pool_size) {
-      const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(need >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)need, 0));
-      const int k = pool_next + rank;
-      pool_next += __popcll(need);
-      const bool take = free_lane & (k < pool_size);
-      const int kk = take ? k : 0;
-      const int c_pix = kk & 63;
-      const int px = tx * 8 + (c_pix & 7);
-      const int row = ty * 8 + (c_pix >> 3);
-      const bool start = take & (px < A.nx) & (row < A.ny);
-      pix = start ? (f * 64 + c_pix) : pix;
-      pixel_id = start ? (unsigned)((A.ny - 1 - row) * A.nx + px) : pixel_id;
-      sample = start ? (unsigned)(A.sample_begin + s_first + (kk >> 6)) : sample;
-      depth = start ? 0 : depth;
-      thr = sel3(start, f3(1.0f, 1.0f, 1.0f), thr);
-      fresh = start;
-      alive |= start;
-      if (STATS) cnt.paths += start;
+    // ---- work items, and (pixel, sample) paths for the free lanes (main.rs:96-101).  Twice when the item the paths
+    // come from runs dry with lanes still free: the next item is opened at once, so no lane waits a traversal phase. ----
+    bool fresh = false, finished = false;
+    int fresh_px = 0, fresh_j = 0;
+    for (int pass = 0; pass < 2; ++pass) {
+      // ======================= work items (wave-uniform) =======================
+      {
+        const bool busy = alive | (GENERAL >= 2 && pend >= 0);
+        if (fill_open && pool_next >= pool_size) fill_open = false;  // slot f goes on as a draining slot
+        unsigned draining = open_mask & ~(fill_open ? (1u << f) : 0u);
+        while (draining != 0u) {
+          const int d = __builtin_ctz(draining);
+          draining &= draining - 1u;
+          if (__ballot(busy & ((pix >> 6) == d)) != 0ull) continue;
+          // the last path of this item has ended: write its tile (main.rs:112-114; sums, not means)
+          const int dtx = slot_info[d][0], dty = slot_info[d][1], chunk = slot_info[d][2];
+          const size_t slab = A.accumulate ? 0 : (size_t)chunk * A.nx * A.ny * 3;
+          const int px = dtx * 8 + (lane & 7);
+          const int row = dty * 8 + (lane >> 3);
+          if (px < A.nx && row < A.ny) {
+            const size_t at = slab + ((size_t)row * A.nx + px) * 3;
+            if (A.accumulate) {
+              // the items of a tile (its sample chunks) meet in the output: hardware float adds, no partial images
+  #pragma unroll
+              for (int c = 0; c < 3; ++c) unsafeAtomicAdd(&out_sum[at + c], acc[c][d * 64 + lane]);
+              if (SUMSQ) {
+  #pragma unroll
+                for (int c = 0; c < 3; ++c) unsafeAtomicAdd(&out_sumsq[at + c], acc[3 + c][d * 64 + lane]);
+              }
+            } else {
+              out_sum[at] = acc[0][d * 64 + lane];
+              out_sum[at + 1] = acc[1][d * 64 + lane];
+              out_sum[at + 2] = acc[2][d * 64 + lane];
+              if (SUMSQ) {
+                out_sumsq[at] = acc[3][d * 64 + lane];
+                out_sumsq[at + 1] = acc[4][d * 64 + lane];
+                out_sumsq[at + 2] = acc[5][d * 64 + lane];
+              }
+            }
+          }
+          open_mask &= ~(1u << d);
+        }
+        if (!fill_open && !queue_empty && open_mask != (1u << RT_SLOTS) - 1u) {
+          int item = 0;
+          if (lane == 0) item = (int)atomicAdd(queue, 1u);
+          item = __builtin_amdgcn_readfirstlane(item);
+          if (item >= n_items) {
+            queue_empty = true;
+          } else {
+            f = __builtin_ctz(~open_mask);
+            const int chunk = item / n_tiles;
+            const int tile = item - chunk * n_tiles;
+            tx = tile % A.tiles_x;
+            ty = tile / A.tiles_x;
+            bool mine = true;
+            if (A.shard_count > 1) {
+              const int blocks_x = (A.nx + 63) / 64;
+              const int block = A.shard_index + (tile >> 6) * A.shard_count;
+              tx = (block % blocks_x) * 8 + (tile & 7);
+              ty = (block / blocks_x) * 8 + ((tile >> 3) & 7);
+              mine = (tx < A.tiles_x) & (ty < A.tiles_y);
+            }
+  #pragma unroll
+            for (int c = 0; c < (SUMSQ ? 6 : 3); ++c) acc[c][f * 64 + lane] = 0.0f;
+            if (lane == 0) {
+              slot_info[f][0] = tx;
+              slot_info[f][1] = ty;
+              slot_info[f][2] = chunk;
+            }
+            // the last chunk comes in halving parts (see render_kernel)
+            const int n_whole = A.n_chunks - A.split_parts;
+            int s_len = A.chunk_spp;
+            s_first = chunk * A.chunk_spp;
+            if (chunk >= n_whole) {
+              const int k = chunk - n_whole;
+              const int last = A.spp - n_whole * A.chunk_spp;
+              const int o0 = last - (last >> k);
+              const int o1 = k + 1 < A.split_parts ? last - (last >> (k + 1)) : last;
+              s_first = n_whole * A.chunk_spp + o0;
+              s_len = o1 - o0;
+            }
+            pool_size = mine ? 64 * s_len : 0;
+            pool_next = 0;
+            open_mask |= 1u << f;
+            fill_open = true;
+          }
+        }
+        if (open_mask == 0u && queue_empty) {
+          finished = true;
+          break;
+        }
+      }
+      // A path that ended on a textured light keeps its lane until the colour has been added (top of the next shading phase).
+      const bool free_lane = ready & !alive & !(GENERAL >= 2 && pend >= 0);
+      const unsigned long long need = __ballot(free_lane);
+      if (need == 0ull) break;
+      if (fill_open && pool_next < pool_size) {
+        const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(need >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)need, 0));
+        const int k = pool_next + rank;
+        pool_next += __popcll(need);
+        const bool take = free_lane & (k < pool_size);
+        const int kk = take ? k : 0;
+        const int c_pix = kk & 63;
+        const int px = tx * 8 + (c_pix & 7);
+        const int row = ty * 8 + (c_pix >> 3);
+        const bool start = take & (px < A.nx) & (row < A.ny);
+        pix = start ? (f * 64 + c_pix) : pix;
+        pixel_id = start ? (unsigned)((A.ny - 1 - row) * A.nx + px) : pixel_id;
+        sample = start ? (unsigned)(A.sample_begin + s_first + (kk >> 6)) : sample;
+        depth = start ? 0 : depth;
+        thr = sel3(start, f3(1.0f, 1.0f, 1.0f), thr);
+        fresh |= start;
+        fresh_px = start ? px : fresh_px;
+        fresh_j = start ? A.ny - 1 - row : fresh_j;
+        alive |= start;
+        if (STATS) cnt.paths += start;
+      }
+      if (pool_next < pool_size || queue_empty) break;  // lanes are only left free by an item that ran dry
     }
+    if (finished) break;
+    RT_STAMP(4);  // work items, refill
     if (__ballot(alive) == 0ull) continue;  // nothing to trace: back to the items (a pool at the image's edge, a pending colour)
     // ---- camera ray of the fresh lanes (main.rs:102-105, camera.rs:53-62); word 0 of the vertex's Philox call ----
     if (__ballot(fresh) != 0ull) {
       const U4 w = philox4x32_10(pixel_id, sample, 0u, 0u, key0, key1);
-      const int px = tx * 8 + (pix & 7);
-      const int j = A.ny - 1 - (ty * 8 + ((pix >> 3) & 7));
+      const int px = fresh_px, j = fresh_j;  // (not from tx, ty: a lane of this phase may belong to the item before)
       const float u = ((float)px + (float)(w.x >> 16) * (1.0f / 65536.0f)) * A.inv_nx;
       const float v = ((float)j + (float)(w.x & 0xffffu) * (1.0f / 65536.0f)) * A.inv_ny;
       int c0 = 0;
@@ -1954,7 +1979,7 @@ __global__ void __launch_bounds__(64, GENERAL < 2 ? RT_STACK_WAVES : 5) render_s
       ro = sel3(fresh, org, ro);
       rd = sel3(fresh, dir, rd);
     }
-    RT_STAMP(4);  // refill + camera
+    RT_STAMP(4);  // camera
     // ---- world.hit(r, 0.001, INFINITY), main.rs:166: the lanes with a new segment start at the root ----
     {
       const bool go = ready & alive;
@@ -2767,13 +2792,22 @@ int launch_render(rt_ctx* ctx, const rt_camera* cam, const rt_render_params* p, 
   // waves) or the last round leaves most of the chip idle.  Split the samples
   // of each tile until there are about 30 rounds of items, but keep at least 32
   // samples per item (the pool's own tail) and the slabs under 1 GiB.
+  const int trav = ctx->dev.stack_mode ? TRAV_STACK : (ctx->dev.flat ? TRAV_FLAT : TRAV_SCAN);
+  // The stack-traversal kernel ADDS an item's tile sums into the zeroed output with hardware float adds: no partial
+  // images and no reduction pass, so the last chunk of a tile's samples can be halved much further than the partial
+  // images of the other kernels allow, and the launch ends on short items (the cost of a tile varies several-fold
+  // across an image with media; a short launch, one shard of eight, lost a quarter of its time to its last items).
+  // (The order of those adds depends on scheduling, so a pixel's sum can differ in its last bits from run to run;
+  // the flat and scan kernels keep their fixed order.)
+  A.accumulate = (trav == TRAV_STACK && !getenv("RT_NO_ACCUMULATE")) ? 1 : 0;  // (the variable: A/B against partial images)
   const long long want_items = 256LL * 24 * 30;
   long long chunks = (want_items + n_tiles - 1) / n_tiles;
-  const long long max_by_spp = p->spp / 32 > 1 ? p->spp / 32 : 1;
+  const int min_chunk_spp = A.accumulate ? 16 : 32;
+  const long long max_by_spp = p->spp / min_chunk_spp > 1 ? p->spp / min_chunk_spp : 1;
   if (chunks > max_by_spp) chunks = max_by_spp;
-  if ((n % 4) != 0) chunks = 1;  // the slab reduction works on float4
+  if (!A.accumulate && (n % 4) != 0) chunks = 1;  // the slab reduction works on float4
   const size_t per_image = n * (d_sumsq ? 2 : 1);
-  while (chunks > 1 && (size_t)chunks * per_image * sizeof(float) > ((size_t)1 << 30)) --chunks;
+  while (!A.accumulate && chunks > 1 && (size_t)chunks * per_image * sizeof(float) > ((size_t)1 << 30)) --chunks;
   if (chunks < 1) chunks = 1;
   A.n_chunks = (int)chunks;
   A.chunk_spp = (p->spp + A.n_chunks - 1) / A.n_chunks;
@@ -2781,7 +2815,16 @@ int launch_render(rt_ctx* ctx, const rt_camera* cam, const rt_render_params* p, 
   // the last chunk in up to four halving parts of at least 8 samples (see the kernel; sizes measured
   // on five scenes: smaller parts cost more at the end of each item than they save at the end of the launch)
   A.split_parts = 1;
-  if ((n % 4) == 0) {
+  if (A.accumulate) {
+    // no partial images to pay for: halve further, down to RT_STACK_LAST_SPP samples
+    const int last = p->spp - (A.n_chunks - 1) * A.chunk_spp;
+    int floor_spp = RT_STACK_LAST_SPP;
+    if (const char* e = getenv("RT_STACK_LAST_SPP")) floor_spp = atoi(e) > 0 ? atoi(e) : floor_spp;  // tuning
+    while (A.split_parts < 8 && (last >> A.split_parts) >= floor_spp) {
+      ++A.split_parts;
+      ++A.n_chunks;
+    }
+  } else if ((n % 4) == 0) {
     const int last = p->spp - (A.n_chunks - 1) * A.chunk_spp;
     while (A.split_parts < 4 && (last >> A.split_parts) >= 8 &&
            (size_t)(A.n_chunks + 1) * per_image * sizeof(float) <= ((size_t)1 << 30)) {
@@ -2797,7 +2840,9 @@ int launch_render(rt_ctx* ctx, const rt_camera* cam, const rt_render_params* p, 
   float* k_sum = d_sum;
   float* k_sumsq = d_sumsq;
   unsigned* d_queue = no_alloc ? (unsigned*)ctx->scratch_ptr : ctx->d_queue;
-  if (A.n_chunks > 1 && no_alloc) {
+  if (A.accumulate) {
+    // no partial images: the kernel adds into the output itself
+  } else if (A.n_chunks > 1 && no_alloc) {
     const size_t need = (size_t)A.n_chunks * per_image;
     const size_t room = (RT_NOALLOC_SCRATCH_BYTES - RT_NOALLOC_SLAB_OFFSET) / sizeof(float);
     if (need > room) {
@@ -2829,7 +2874,6 @@ int launch_render(rt_ctx* ctx, const rt_camera* cam, const rt_render_params* p, 
   static const RenderFn table[48] = {RT_ROW(false, false), RT_ROW(false, true), RT_ROW(true, false), RT_ROW(true, true)};
 #undef RT_ROW
 #undef RT_TRIO
-  const int trav = ctx->dev.stack_mode ? TRAV_STACK : (ctx->dev.flat ? TRAV_FLAT : TRAV_SCAN);
 #define RT_STK(ST, SQ) render_stack_kernel<ST, SQ, 0>, render_stack_kernel<ST, SQ, 1>, render_stack_kernel<ST, SQ, 2>, render_stack_kernel<ST, SQ, 3>
   static const RenderFn stack_table[16] = {RT_STK(false, false), RT_STK(false, true), RT_STK(true, false), RT_STK(true, true)};
 #undef RT_STK
@@ -2847,14 +2891,17 @@ int launch_render(rt_ctx* ctx, const rt_camera* cam, const rt_render_params* p, 
   // a launch on another stream than the last one first waits for that one to finish.
   if (ctx->launched && ctx->last_stream != stream) HIP_TRY(hipStreamWaitEvent(stream, ctx->ev_launch, 0));
   HIP_TRY(hipMemsetAsync(d_queue, 0, sizeof(unsigned), stream));
-  if (p->shard_count > 1) {
+  if (A.accumulate) {
+    HIP_TRY(hipMemsetAsync(k_sum, 0, n * sizeof(float), stream));
+    if (k_sumsq) HIP_TRY(hipMemsetAsync(k_sumsq, 0, n * sizeof(float), stream));
+  } else if (p->shard_count > 1) {
     // a shard writes its own tiles only: everything else in the image (or in every partial image) is zero
     HIP_TRY(hipMemsetAsync(k_sum, 0, (size_t)A.n_chunks * n * sizeof(float), stream));
     if (k_sumsq) HIP_TRY(hipMemsetAsync(k_sumsq, 0, (size_t)A.n_chunks * n * sizeof(float), stream));
   }
   hipLaunchKernelGGL(fn, dim3((unsigned)waves), block, lds_bytes, stream, ctx->dev, dc, A, k_sum, k_sumsq, ctx->d_stats, d_queue);
   HIP_TRY(hipGetLastError());
-  if (A.n_chunks > 1) {
+  if (A.n_chunks > 1 && !A.accumulate) {
     const size_t n4 = n / 4;
     unsigned blocks = (unsigned)((n4 + 255) / 256);
     if (blocks > 2048) blocks = 2048;
