@@ -268,7 +268,11 @@ int rt_render(rt_ctx* ctx, const rt_camera* cam, const rt_render_params* params,
  * the other: a launch on another stream than the context's previous launch first
  * waits (on the device) for that launch to end.  To overlap renders, use one
  * context per stream.  A launch that needs a larger partial-image buffer than any
- * before it on this context allocates it during the call (which synchronises). */
+ * before it on this context allocates it during the call (which synchronises).
+ * Scenes of at most 16 leaves and scenes on the skip-link scan give the same bits
+ * on every run.  Scenes on the per-lane stack traversal (larger trees) have no
+ * partial images: their work items add tile sums into the zeroed output with
+ * hardware float adds, so the last bits of a sum can differ from run to run. */
 int rt_render_device(rt_ctx* ctx, const rt_camera* cam, const rt_render_params* params,
                      float* d_sum_rgb, float* d_sumsq_rgb_or_null, void* hip_stream);
 
@@ -285,7 +289,8 @@ int rt_render_device(rt_ctx* ctx, const rt_camera* cam, const rt_render_params* 
  * 256x256 at 1000 spp fits (34 partial images, 27 MB) and so does 1024x1024 at
  * 100 spp (5 partial images, 63 MB); 1024x1024 at 1000 spp does not (15 partial
  * images, 189 MB); any image at fewer than 64 spp does (one chunk, no partial
- * images).
+ * images), and so does any launch of a scene on the per-lane stack traversal (it
+ * has no partial images; see rt_render_device for what that means for its bits).
  * Every call on a GPU, from any context, uses that GPU's one array: calls that
  * overlap on one GPU race (calls of one context are ordered as for
  * rt_render_device; calls of different contexts on one device are the caller's
