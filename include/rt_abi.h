@@ -207,10 +207,25 @@ typedef struct rt_render_params {
   int32_t max_depth;    /* 50 in the reference (src/main.rs:173) */
   int32_t sky;          /* RT_SKY_* */
   float t_min;          /* 0.001 in the reference (src/main.rs:166) */
-  int32_t shard_index;  /* pixel-tile sharding: this call renders only the     */
-  int32_t shard_count;  /* 64x64 tiles t with t % shard_count == shard_index   */
+  int32_t shard_index;  /* pixel-tile sharding: this call renders only the 8x8-pixel */
+  int32_t shard_count;  /* tiles t with t % shard_count == shard_index (see below)  */
   uint64_t seed;        /* Philox key */
 } rt_render_params;
+
+/* Pixel-tile sharding deals 8x8-pixel tiles (tile (0,0) is the image's top left
+ * corner).  Tiles are numbered row by row over a grid rt_shard_width() tiles wide:
+ * the smallest width >= ceil(nx/8) that has no common factor with shard_count, so
+ * that the tiles t = shard_index (mod shard_count) of one shard never line up in
+ * columns; numbers whose column lies beyond the image's edge stand for no tile.
+ * Tile t covers pixels x in [8*(t % w), +8), y in [8*(t / w), +8) (y from the top). */
+static inline int rt_shard_width(int nx, int shard_count) {
+  int w = (nx + 7) / 8;
+  for (;; ++w) {
+    int a = w, b = shard_count > 0 ? shard_count : 1;
+    while (b) { const int r = a % b; a = b; b = r; }
+    if (a == 1 || shard_count <= 1) return w;
+  }
+}
 
 /* Random numbers.  The reference draws everything from rand::thread_rng()
  * (OS seeded, not replayable).  This ABI fixes a counter-based stream instead:
@@ -307,10 +322,10 @@ int rt_render_device_noalloc(rt_ctx* ctx, const rt_camera* cam, const rt_render_
  *   RT_SHARD_SAMPLES  rank g renders samples [g*spp/N, (g+1)*spp/N) of every pixel
  *                     (main.rs:74-78) and the frames are summed onto rank 0
  *                     (main.rs:128-133): nx*ny*12 bytes per rank.
- *   RT_SHARD_TILES    rank g renders the 64x64-pixel blocks b with b % N == g at
- *                     the full sample count; each rank sends only its own blocks
- *                     and rank 0 puts them in place: nx*ny*12/N bytes per rank,
- *                     no arithmetic.
+ *   RT_SHARD_TILES    rank g renders the 8x8-pixel tiles t with t % N == g (numbered
+ *                     as for rt_render_params.shard_index) at the full sample
+ *                     count; each rank sends only its own tiles and rank 0 puts
+ *                     them in place: nx*ny*12/N bytes per rank, no arithmetic.
  * With distinct device ids the exchange is RCCL on the ranks' streams (one
  * communicator per rank from ncclCommInitAll; ncclReduce, or grouped
  * ncclSend/ncclRecv); librccl.so is opened when such a context is created.  With

@@ -804,12 +804,12 @@ void render_rows(const rt_scene* scene, const rt_camera* cam, const rt_render_pa
   typedef typename P::Real R;
   World<P> world(scene);
   const int nx = prm->nx, ny = prm->ny;
+  const int shard_width = rt_shard_width(nx, prm->shard_count);
   // main.rs:96-116
   for (int j = j_end - 1; j >= j_begin; --j) {
     for (int i = 0; i < nx; ++i) {
       if (prm->shard_count > 1) {
-        const int tiles_x = (nx + 63) / 64;
-        const int tile = ((ny - 1 - j) / 64) * tiles_x + i / 64;
+        const int tile = ((ny - 1 - j) / 8) * shard_width + i / 8;  // numbered as include/rt_abi.h describes
         if (tile % prm->shard_count != prm->shard_index) continue;
       }
       double acc[3] = {0, 0, 0}, acc2[3] = {0, 0, 0};

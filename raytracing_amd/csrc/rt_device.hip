@@ -1342,8 +1342,8 @@ __device__ __forceinline__ Shaded shade_vertex(const DevScene& S, const float4* 
 struct RenderArgs {
   int nx, ny, spp, sample_begin, max_depth, sky;
   float t_min, inv_nx, inv_ny;
-  int shard_index, shard_count;
-  int n_tiles;  // tiles this launch works on: all of them, or 64 per 64x64-pixel block of this shard
+  int shard_index, shard_count, shard_width;
+  int n_tiles;  // tiles this launch works on: all of them, or this shard's tile numbers (some of them beyond the image's edge)
   unsigned key0, key1;
   int tiles_x, tiles_y;
   int n_chunks, chunk_spp;  // the samples of a tile are split into n_chunks work items of chunk_spp samples,
@@ -1431,12 +1431,12 @@ __global__ void __launch_bounds__(64, (TRAV == TRAV_STACK && GENERAL < 2) ? 6 : 
   int tx = tile % A.tiles_x, ty = tile / A.tiles_x;
   bool mine = true;
   if (A.shard_count > 1) {
-    // A shard's launch runs over its own 64x64-pixel blocks only (block b belongs to shard b % shard_count): 64 tiles
-    // per block, those beyond the image's edge empty.  The host has zeroed the output, so other shards' pixels stay 0.
-    const int blocks_x = (A.nx + 63) / 64;
-    const int block = A.shard_index + (tile >> 6) * A.shard_count;
-    tx = (block % blocks_x) * 8 + (tile & 7);
-    ty = (block / blocks_x) * 8 + ((tile >> 3) & 7);
+    // A shard's launch runs over its own tiles only: the numbers shard_index + k * shard_count of a grid shard_width
+    // tiles wide (rt_shard_width), columns beyond the image's edge empty.  The host has zeroed the output, so other
+    // shards' pixels stay 0.
+    const int t = A.shard_index + tile * A.shard_count;
+    tx = t % A.shard_width;
+    ty = t / A.shard_width;
     mine = (tx < A.tiles_x) & (ty < A.tiles_y);
   }
   const size_t slab = (size_t)chunk * A.nx * A.ny * 3;
@@ -1880,10 +1880,9 @@ __global__ void __launch_bounds__(64, GENERAL < 2 ? RT_STACK_WAVES : 5) render_s
             ty = tile / A.tiles_x;
             bool mine = true;
             if (A.shard_count > 1) {
-              const int blocks_x = (A.nx + 63) / 64;
-              const int block = A.shard_index + (tile >> 6) * A.shard_count;
-              tx = (block % blocks_x) * 8 + (tile & 7);
-              ty = (block / blocks_x) * 8 + ((tile >> 3) & 7);
+              const int t = A.shard_index + tile * A.shard_count;
+              tx = t % A.shard_width;
+              ty = t / A.shard_width;
               mine = (tx < A.tiles_x) & (ty < A.tiles_y);
             }
   #pragma unroll
@@ -2776,13 +2775,14 @@ int launch_render(rt_ctx* ctx, const rt_camera* cam, const rt_render_params* p, 
   A.tiles_x = (p->nx + 7) / 8; A.tiles_y = (p->ny + 7) / 8;
   const size_t n = (size_t)p->nx * p->ny * 3;
   int n_tiles = A.tiles_x * A.tiles_y;
+  A.shard_width = rt_shard_width(p->nx, p->shard_count);
   if (p->shard_count > 1) {
-    const int n_blocks = ((p->nx + 63) / 64) * ((p->ny + 63) / 64);
-    const int mine = (n_blocks - p->shard_index + p->shard_count - 1) / p->shard_count;  // blocks b = shard_index (mod shard_count)
-    n_tiles = mine * 64;
+    const long long numbers = (long long)A.shard_width * A.tiles_y;  // tile numbers t = shard_index (mod shard_count) below this
+    if (numbers + p->shard_count > 0x7fffffffLL) return rt::set_error(RT_ERR_UNSUPPORTED, "image too large for tile sharding");
+    n_tiles = p->shard_index < numbers ? (int)((numbers - p->shard_index + p->shard_count - 1) / p->shard_count) : 0;
   }
   A.n_tiles = n_tiles;
-  if (n_tiles == 0) {  // more shards than blocks: this one has nothing to render
+  if (n_tiles == 0) {  // more shards than tiles: this one has nothing to render
     HIP_TRY(hipMemsetAsync(d_sum, 0, n * sizeof(float), stream));
     if (d_sumsq) HIP_TRY(hipMemsetAsync(d_sumsq, 0, n * sizeof(float), stream));
     return RT_OK;
@@ -2800,9 +2800,11 @@ int launch_render(rt_ctx* ctx, const rt_camera* cam, const rt_render_params* p, 
   // (The order of those adds depends on scheduling, so a pixel's sum can differ in its last bits from run to run;
   // the flat and scan kernels keep their fixed order.)
   A.accumulate = (trav == TRAV_STACK && !getenv("RT_NO_ACCUMULATE")) ? 1 : 0;  // (the variable: A/B against partial images)
-  const long long want_items = 256LL * 24 * 30;
+  long long want_items = 256LL * 24 * 30;
+  int min_chunk_spp = A.accumulate ? 16 : 32;
+  if (const char* e = getenv("RT_WANT_ROUNDS")) want_items = 256LL * 24 * (atoi(e) > 0 ? atoi(e) : 30);  // tuning
+  if (const char* e = getenv("RT_MIN_CHUNK_SPP")) min_chunk_spp = atoi(e) > 0 ? atoi(e) : min_chunk_spp;
   long long chunks = (want_items + n_tiles - 1) / n_tiles;
-  const int min_chunk_spp = A.accumulate ? 16 : 32;
   const long long max_by_spp = p->spp / min_chunk_spp > 1 ? p->spp / min_chunk_spp : 1;
   if (chunks > max_by_spp) chunks = max_by_spp;
   if (!A.accumulate && (n % 4) != 0) chunks = 1;  // the slab reduction works on float4

@@ -7,8 +7,9 @@
 //   RT_SHARD_SAMPLES: rank g renders samples [g*spp/N, (g+1)*spp/N) of every pixel
 //                     (what main.rs:74-78 does with threads); the frames are SUMMED
 //                     onto rank 0 (main.rs:128-133).
-//   RT_SHARD_TILES:   rank g renders the 64x64-pixel blocks b with b % N == g at the
-//                     full sample count; each rank packs its own blocks into a
+//   RT_SHARD_TILES:   rank g renders the 8x8-pixel tiles t with t % N == g (numbered as
+//                     rt_abi.h describes for rt_render_params.shard_index) at the
+//                     full sample count; each rank packs its own tiles into a
 //                     contiguous buffer and rank 0 GATHERS them: nx*ny*12/N bytes per
 //                     rank on the wire and no arithmetic.
 // The exchange is RCCL (ncclReduce / grouped ncclSend+ncclRecv, one communicator per
@@ -93,24 +94,21 @@ __global__ void __launch_bounds__(256) add_frames_kernel(float* __restrict__ dst
   for (size_t i = n4 * 4 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] += src[i];
 }
 
-// The k-th 64x64 block of shard `index` of `count` is block index + k*count of the frame (blocks counted row by row).
-// Packed layout: block k at packed[k * 64*64*3], rows of 64 pixels, pixels beyond the frame's edge unused.
-// PACK copies frame -> packed, !PACK copies packed -> frame.  One thread per (block row, float) = 192 threads per row.
+// The k-th tile of shard `index` of `count` is tile number index + k*count of a grid `width` tiles wide (rt_shard_width).
+// Packed layout: tile k at packed[k * 8*8*3], rows of 8 pixels; tiles and pixels beyond the frame's edge unused.
+// PACK copies frame -> packed, !PACK copies packed -> frame.  One thread per float of a tile, one tile per 192 threads.
 template <bool PACK>
 __global__ void __launch_bounds__(192) move_blocks_kernel(float* __restrict__ frame, float* __restrict__ packed, int nx, int ny, int index,
-                                                         int count, int n_mine) {
-  const int blocks_x = (nx + 63) / 64;
-  const int k = blockIdx.x >> 6, row_in = blockIdx.x & 63;
+                                                         int count, int width, int n_mine) {
+  const int k = blockIdx.x;
   if (k >= n_mine) return;
-  const int b = index + k * count;
-  const int bx = b % blocks_x, by = b / blocks_x;
-  const int y = by * 64 + row_in;
-  if (y >= ny) return;
-  const int x0 = bx * 64;
-  const int c = threadIdx.x;  // float within the row of the block: 64 pixels x 3
-  if (x0 + c / 3 >= nx) return;
+  const int t = index + k * count;
+  const int x0 = (t % width) * 8, y0 = (t / width) * 8;
+  const int c = threadIdx.x % 24, row = threadIdx.x / 24;  // float within the tile's row (8 pixels x 3), row of the tile
+  const int y = y0 + row;
+  if (y >= ny || x0 + c / 3 >= nx) return;
   float* f = frame + ((size_t)y * nx + x0) * 3 + c;
-  float* p = packed + ((size_t)k * 64 + row_in) * 192 + c;
+  float* p = packed + (size_t)k * 192 + threadIdx.x;
   if (PACK) *p = *f;
   else *f = *p;
 }
@@ -155,9 +153,10 @@ int nccl_fail(const Rccl* r, int code, const char* what) {
     if (c_ != 0) return nccl_fail((m)->rccl, c_, #expr);       \
   } while (0)
 
+// how many tile numbers shard `index` of `count` has (the launch's own count, rt_device.hip)
 int blocks_of(int nx, int ny, int index, int count) {
-  const int n_blocks = ((nx + 63) / 64) * ((ny + 63) / 64);
-  return index < n_blocks ? (n_blocks - index + count - 1) / count : 0;
+  const long long numbers = (long long)rt_shard_width(nx, count) * ((ny + 7) / 8);
+  return index < numbers ? (int)((numbers - index + count - 1) / count) : 0;
 }
 
 // Sums (samples) or gathers (tiles) the ranks' buffers `buf` (frames) onto rank 0's frame.
@@ -166,7 +165,7 @@ int exchange(rt_multi* m, const rt_render_params* p, int shard_mode, std::vector
   const size_t n = (size_t)p->nx * p->ny * 3;
   const int N = m->n;
   if (N == 1) return RT_OK;
-  const size_t block_floats = 64 * 64 * 3;
+  const size_t block_floats = 8 * 8 * 3;
   if (shard_mode == RT_SHARD_TILES) {
     // every other rank packs its blocks
     for (int r = 1; r < N; ++r) {
@@ -175,7 +174,7 @@ int exchange(rt_multi* m, const rt_render_params* p, int shard_mode, std::vector
       if (rc != RT_OK) return rc;
       if (mine == 0) continue;
       HIP_TRY(hipSetDevice(m->device[r]));
-      hipLaunchKernelGGL(move_blocks_kernel<true>, dim3((unsigned)mine * 64), dim3(192), 0, m->stream[r], frame[r], packed[r], p->nx, p->ny, r, N, mine);
+      hipLaunchKernelGGL(move_blocks_kernel<true>, dim3((unsigned)mine), dim3(192), 0, m->stream[r], frame[r], packed[r], p->nx, p->ny, r, N, rt_shard_width(p->nx, N), mine);
       HIP_TRY(hipGetLastError());
     }
   }
@@ -212,7 +211,7 @@ int exchange(rt_multi* m, const rt_render_params* p, int shard_mode, std::vector
     for (int r = 1; r < N; ++r) {
       const int mine = blocks_of(p->nx, p->ny, r, N);
       if (mine == 0) continue;
-      hipLaunchKernelGGL(move_blocks_kernel<false>, dim3((unsigned)mine * 64), dim3(192), 0, m->stream[0], frame[0], m->stage + at[(size_t)r], p->nx, p->ny, r, N, mine);
+      hipLaunchKernelGGL(move_blocks_kernel<false>, dim3((unsigned)mine), dim3(192), 0, m->stream[0], frame[0], m->stage + at[(size_t)r], p->nx, p->ny, r, N, rt_shard_width(p->nx, N), mine);
     }
     HIP_TRY(hipGetLastError());
     return RT_OK;
@@ -232,7 +231,7 @@ int exchange(rt_multi* m, const rt_render_params* p, int shard_mode, std::vector
     const float* src = shard_mode == RT_SHARD_TILES ? packed[r] : frame[r];
     HIP_TRY(hipMemcpyAsync(m->stage, src, cnt * sizeof(float), hipMemcpyDeviceToDevice, m->stream[0]));
     if (shard_mode == RT_SHARD_TILES) {
-      hipLaunchKernelGGL(move_blocks_kernel<false>, dim3((unsigned)mine * 64), dim3(192), 0, m->stream[0], frame[0], m->stage, p->nx, p->ny, r, N, mine);
+      hipLaunchKernelGGL(move_blocks_kernel<false>, dim3((unsigned)mine), dim3(192), 0, m->stream[0], frame[0], m->stage, p->nx, p->ny, r, N, rt_shard_width(p->nx, N), mine);
     } else {
       unsigned blocks = (unsigned)((n / 4 + 255) / 256);
       if (blocks > 2048) blocks = 2048;

@@ -6,8 +6,9 @@ The reference spreads work over its 8 threads by giving each thread every pixel
 at ns/8 samples and summing the 8 images under a mutex (src/main.rs:74-78,
 128-133).  `shard_params(..., mode="samples")` is that split with ranks for
 threads, and `reduce_to_root` is the sum.  `mode="tiles"` gives each rank a
-disjoint set of 64x64 pixel tiles at the full sample count instead; the other
-ranks leave those pixels zero, so the same sum gathers the image.
+disjoint set of 8x8 pixel tiles at the full sample count instead (dealt as
+include/rt_abi.h describes; `shard_width` and `shard_tile_mask` restate it); the
+other ranks leave those pixels zero, so the same sum gathers the image.
 
 Because every (pixel, sample) has its own Philox counter, the result does not
 depend on how the work was split, only on fp32 summation order.
@@ -43,6 +44,25 @@ def shard_params(params, rank, world, mode="samples"):
     else:
         raise ValueError("mode must be 'samples' or 'tiles'")
     return p
+
+
+def shard_width(nx, world):
+    """rt_shard_width of include/rt_abi.h: the smallest grid width >= ceil(nx/8)
+    tiles with no common factor with `world`."""
+    from math import gcd
+    w = (nx + 7) // 8
+    while world > 1 and gcd(w, world) != 1:
+        w += 1
+    return w
+
+
+def shard_tile_mask(nx, ny, rank, world):
+    """Boolean (ny, nx) array, rows from the top: the pixels of the 8x8 tiles
+    rank `rank` of `world` renders in mode "tiles"."""
+    import numpy as np
+    w = shard_width(nx, world)
+    ty, tx = np.meshgrid(np.arange(ny) // 8, np.arange(nx) // 8, indexing="ij")
+    return (ty * w + tx) % world == rank
 
 
 def reduce_to_root(tensor, group=None, root=0):

@@ -77,3 +77,28 @@ def test_shard_params_cover_every_sample_once():
             shard_params(make_params(8, 8, 3), r, 8, "samples")
     with pytest.raises(ValueError):
         shard_params(p, 4, 4, "samples")
+
+
+def test_tile_shards_of_the_oracle_follow_the_documented_numbering(orc, cornell):
+    """The oracle's tile shards light exactly the pixels shard_tile_mask names (the
+    restatement of include/rt_abi.h's numbering), for a shard count that shares a
+    factor with the tiles of a row (the grid is then one tile wider) and one that
+    does not; and no shard's tiles line up in columns."""
+    from raytracing_amd import make_params
+    from raytracing_amd.distributed import shard_tile_mask, shard_width
+    nx, ny = 80, 76  # 10 x 10 tiles, the last row cut
+    assert shard_width(nx, 5) == 11 and shard_width(nx, 3) == 10 and shard_width(nx, 1) == 10
+    for count in (3, 5):
+        seen = np.zeros((ny, nx), dtype=int)
+        for k in range(count):
+            part, _ = orc.render(cornell.flat, cornell.camera.c, make_params(nx, ny, 4, seed=5, shard_index=k, shard_count=count),
+                                 mode=orc.ORC_F32, n_threads=4)
+            lit = part.sum(axis=2) > 0
+            mask = shard_tile_mask(nx, ny, k, count)
+            assert not lit[~mask].any()
+            lit_tiles = np.add.reduceat(np.add.reduceat(lit, np.arange(0, ny, 8), axis=0), np.arange(0, nx, 8), axis=1) > 0
+            assert np.array_equal(lit_tiles, mask[::8, ::8])  # every tile of the shard has lit pixels
+            seen += mask
+            cols = mask[::8, ::8]  # one entry per tile
+            assert cols.any(axis=0).all()  # every column of tiles has tiles of every shard
+        assert (seen == 1).all()

@@ -9,6 +9,7 @@ import pytest
 
 from raytracing_amd import Scene, make_params
 from raytracing_amd import scenes
+from raytracing_amd.distributed import shard_tile_mask
 
 pytestmark = pytest.mark.gpu
 
@@ -90,8 +91,8 @@ def test_million_sphere_device_built_tree_nearest_hits(gpu, orc, stress_scene):
 
 def test_million_sphere_render_at_3840x2160(gpu, orc, stress_scene):
     """The named frame at one sample per pixel.  The oracle takes a minute for the
-    whole frame, so it renders every 40th 64x64 block (tile shard 7 of 40) and the
-    device frame is compared on those blocks; the whole frame is checked through
+    whole frame, so it renders every 40th 8x8 tile (tile shard 7 of 40) and the
+    device frame is compared on those tiles; the whole frame is checked through
     its event counts and through the same tile shard rendered by the device."""
     cam, flat = stress_scene
     gpu.upload_scene(flat)
@@ -105,10 +106,7 @@ def test_million_sphere_render_at_3840x2160(gpu, orc, stress_scene):
     mask = part.sum(axis=2) != 0
     assert np.array_equal(part[mask], s[mask])
     o = orc.render(flat, cam.c, q, mode=orc.ORC_F32_FUSED, n_threads=16, want_sumsq=False).astype(np.float32)
-    blocks = np.zeros((ny, nx), dtype=bool)
-    for b in range(7, 60 * 34, 40):
-        by, bx = divmod(b, 60)
-        blocks[by * 64:(by + 1) * 64, bx * 64:(bx + 1) * 64] = True
+    blocks = shard_tile_mask(nx, ny, 7, 40)
     assert not part[~blocks].any() and not o[~blocks].any()
     a, b = part[blocks], o[blocks]
     assert np.isclose(a, b, rtol=5e-3, atol=5e-3).mean() > 0.9, np.isclose(a, b, rtol=5e-3, atol=5e-3).mean()

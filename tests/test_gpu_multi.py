@@ -38,7 +38,7 @@ def test_virtual_ranks_reproduce_the_one_rank_image(gpu, cornell, n_ranks):
     to fp32 summation order; by tiles the gathered image equals, bit for bit, the
     tile shards rendered one by one through rt_render and added."""
     gpu.upload_scene(cornell.flat)
-    nx, ny, spp = 200, 136, 48  # 4 x 3 blocks of 64x64, the last column and row ragged
+    nx, ny, spp = 200, 133, 48  # 25 x 17 tiles, the last row cut; 8 ranks deal over a grid 25 wide, 5 ranks would need 26
     p = make_params(nx, ny, spp, seed=17)
     whole, whole2 = gpu.render(cornell.camera, p, want_sumsq=True)
     m = MultiRenderer([0] * n_ranks)
@@ -59,23 +59,24 @@ def test_virtual_ranks_reproduce_the_one_rank_image(gpu, cornell, n_ranks):
 
 
 def test_more_ranks_than_blocks_and_a_tree_scene(gpu, orc):
-    """100x60 pixels are two 64x64 blocks: with five ranks three have nothing to
-    render.  The scene is a sphere field on the stack traversal, whose per-pixel
+    """16x8 pixels are two tiles: with five ranks three have nothing to render;
+    100x60 is an ordinary small frame.  The scene is a sphere field on the stack traversal, whose per-pixel
     sums depend on scheduling in their last bits, hence the tolerance."""
     from test_gpu_materials import _sphere_field
     with Scene(61) as sc:
         cam, world = _sphere_field(120, 5, glass_and_metal=False)
         flat = sc.flatten(world)
     gpu.upload_scene(flat)
-    p = make_params(100, 60, 32, seed=8)
-    whole = gpu.render(cam, p)
     m = MultiRenderer([0] * 5)
     try:
         m.upload_scene(flat)
-        for mode in ("tiles", "samples"):
-            s = m.render(cam, p, mode=mode)
-            assert np.allclose(s, whole, rtol=1e-5, atol=1e-4), mode
-            assert s.sum() > 0
+        for nx, ny in ((16, 8), (100, 60)):
+            p = make_params(nx, ny, 32, seed=8)
+            whole = gpu.render(cam, p)
+            for mode in ("tiles", "samples"):
+                s = m.render(cam, p, mode=mode)
+                assert np.allclose(s, whole, rtol=1e-5, atol=1e-4), (mode, nx)
+                assert s.sum() > 0
     finally:
         m.close()
 
