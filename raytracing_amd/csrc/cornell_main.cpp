@@ -97,7 +97,7 @@ int main(int argc, char** argv) {
   const std::string path = argc > 3 ? argv[3] : "cornell_box.png";
   const unsigned long long seed = argc > 4 ? std::strtoull(argv[4], nullptr, 0) : 0x5EED0001ull;
   // The reference spreads the samples over 8 threads (main.rs:70); here over `gpus` GPUs of the node (devices 0..gpus-1).
-  // A negative count gives that many ranks that all share GPU 0; "tiles" splits the image by 64x64 blocks instead of samples.
+  // A negative count gives that many ranks that all share GPU 0; "tiles" splits the image by 8x8 tiles instead of samples.
   const long gpus = argc > 5 ? std::atol(argv[5]) : 1;
   const bool by_tiles = argc > 6 && std::strcmp(argv[6], "tiles") == 0;
   if (factor <= 0 || quality <= 0 || gpus == 0 || gpus > 64 || gpus < -64) {
