@@ -727,31 +727,25 @@ __device__ __forceinline__ void leaf_list_lane(const DevScene& S, int first, int
   else prim_list_lane<STATS>(S, first, count, r, t_min, t_max, best, cnt);
 }
 
-// The lane's stack: a column of LDS (consecutive entries 64 dwords apart), sized by the launch to what the deepest
-// walk of the scene can need.  RT_STACK_PRIVATE > 0 builds a variant that keeps only the first RT_STACK_LDS entries
-// in LDS and deeper ones in the lane's private memory; measured, the private array costs more (13 % on the Book-1
-// scene) than the LDS it frees gains, so the default is LDS only and a tree whose walk could need more than
-// RT_STACK_LDS entries takes the scan traversal instead.
-#ifndef RT_STACK_PRIVATE
-#define RT_STACK_PRIVATE 0
+// The lane's stack: a column of LDS (consecutive entries 64 dwords apart).  A walk's worst case (three waiting
+// descendants per level) is several times what walks really use, and the LDS a wave holds decides how many waves a
+// CU runs, which is what hides the node fetches: so the render kernel keeps only the first n_lds entries in LDS and
+// the deeper ones in a column of global memory of the wave's own (`ovf`, same layout), touched by the rare walk that
+// gets that deep.  The trace kernel keeps the whole stack in LDS (n_lds = the scene's depth, ovf unused).
+#define RT_STACK_MAX 64  // deepest walk the stack traversal takes (LDS + overflow)
+#ifndef RT_STACK_LDS_RENDER
+#define RT_STACK_LDS_RENDER 12  // entries the render kernel keeps in LDS
 #endif
-#ifndef RT_STACK_LDS
-#define RT_STACK_LDS 64
-#endif
-struct LaneStack {
+template <bool OVF>
+struct LaneStackT {
   unsigned* lds;  // this lane's column
   int n_lds;      // entries in LDS
-#if RT_STACK_PRIVATE > 0
-  unsigned deep[RT_STACK_PRIVATE];
+  unsigned* ovf;  // this lane's column of the wave's overflow region (OVF only)
   __device__ __forceinline__ void put(int at, unsigned v) {
-    if (at < n_lds) lds[at * 64] = v;
-    else deep[at - n_lds] = v;
+    if (!OVF || at < n_lds) lds[at * 64] = v;
+    else ovf[(at - n_lds) * 64] = v;
   }
-  __device__ __forceinline__ unsigned get(int at) const { return at < n_lds ? lds[at * 64] : deep[at - n_lds]; }
-#else
-  __device__ __forceinline__ void put(int at, unsigned v) { lds[at * 64] = v; }
-  __device__ __forceinline__ unsigned get(int at) const { return lds[at * 64]; }
-#endif
+  __device__ __forceinline__ unsigned get(int at) const { return (!OVF || at < n_lds) ? lds[at * 64] : ovf[(at - n_lds) * 64]; }
 };
 
 // The state of one lane's walk through the four-wide tree.
@@ -781,8 +775,8 @@ __device__ __forceinline__ int trav_enter(const DevScene& S, int ref, int box, c
 // test its boxes and go to the nearest descendant the ray enters, pushing the others farthest first.  Returns false
 // when the walk has ended.  (Leaves, single primitives included, are left to trav_leaf: the wave runs that code for
 // many lanes at once, which was measured faster than testing a primitive where a lane meets it.)
-template <bool STATS>
-__device__ __forceinline__ bool trav_step(const DevScene& S, LaneStack& stk, Trav& T, const RayF& w, float t_min, float t_max, Counters& cnt) {
+template <bool STATS, class STK>
+__device__ __forceinline__ bool trav_step(const DevScene& S, STK& stk, Trav& T, const RayF& w, float t_min, float t_max, Counters& cnt) {
   if (T.cur == TRAV_POP) {
     if (T.sp == 0) return false;
     --T.sp;
@@ -832,8 +826,8 @@ __device__ __forceinline__ bool trav_step(const DevScene& S, LaneStack& stk, Tra
 // The leaf a lane holds (its box has been passed): a primitive list in the current frame, or an object:
 // Translate/RotateY over a list or over a BvhNode, whose sub-tree the lane enters in the object's frame with a
 // marker on the stack that switches it back.  ConstantMedium leaves are left to the caller (they draw random numbers).
-template <bool STATS>
-__device__ __forceinline__ void trav_leaf(const DevScene& S, LaneStack& stk, Trav& T, const RayF& w, float t_min, float t_max, Counters& cnt) {
+template <bool STATS, class STK>
+__device__ __forceinline__ void trav_leaf(const DevScene& S, STK& stk, Trav& T, const RayF& w, float t_min, float t_max, Counters& cnt) {
   const int node = T.cur & BN_INDEX_MASK;
   const bool single = (T.cur & BN2_PRIM) != 0;
   T.cur = TRAV_POP;
@@ -870,9 +864,10 @@ __device__ __forceinline__ void trav_leaf(const DevScene& S, LaneStack& stk, Tra
 template <bool STATS>
 __device__ __forceinline__ void trace_stack(const DevScene& S, unsigned* __restrict__ stk_lds, const RayF& w, float t_min, float t_max, Hit& best,
                                             Counters& cnt) {
-  LaneStack stk;
+  LaneStackT<false> stk;
   stk.lds = stk_lds;
   stk.n_lds = S.stack_lds;
+  stk.ovf = nullptr;
   Trav T;
   T.r = w;
   T.sp = 0;
@@ -1351,6 +1346,8 @@ struct RenderArgs {
   int ready_lanes;          // render_stack_kernel: finished rays in a wave (in 64 live ones) that end a traversal phase
   int hold_lanes;           // and lanes holding a leaf (in 64 traversing ones) that make the wave run the leaf code
   int accumulate;           // render_stack_kernel: items ADD their tile sums to the (zeroed) output instead of writing partial images
+  int stack_lds;            // render_stack_kernel: entries of a lane's stack kept in LDS; deeper ones go to stack_ovf
+  unsigned* stack_ovf;      // (scene's stack depth - stack_lds) x 64 dwords for every wave of the grid
 };
 
 // Waves per SIMD the register allocator must leave room for (launch_bounds' second argument).
@@ -1693,10 +1690,11 @@ __global__ void __launch_bounds__(64, GENERAL < 2 ? RT_STACK_WAVES : 5) render_s
   // that slot's accumulators; a slot's tile is written when its last path has ended.
   __shared__ float acc[SUMSQ ? 6 : 3][RT_SLOTS * 64];
   __shared__ int slot_info[RT_SLOTS][4];  // tile x, tile y, chunk
-  extern __shared__ float4 prim_lds[];  // the LDS part of the traversal stack: stack_lds entries of 64 lanes
-  LaneStack stk;
+  extern __shared__ float4 prim_lds[];  // the LDS part of the traversal stack: A.stack_lds entries of 64 lanes
+  LaneStackT<true> stk;
   stk.lds = (unsigned*)prim_lds + (threadIdx.x & 63);
-  stk.n_lds = S.stack_lds;
+  stk.n_lds = A.stack_lds;
+  stk.ovf = A.stack_ovf + (size_t)blockIdx.x * (size_t)(S.stack_depth - A.stack_lds) * 64 + (threadIdx.x & 63);
   const int lane = threadIdx.x & 63;
   __shared__ float cam_lds[20];
   if (lane == 0) {
@@ -2127,6 +2125,8 @@ struct rt_ctx {
   void* d_lights;
   unsigned long long* d_stats;
   unsigned* d_queue;    // the work-item counter of render_kernel
+  unsigned* d_stack_ovf;  // render_stack_kernel: the deep ends of the lanes' stacks (grown on demand)
+  size_t stack_ovf_bytes;
   int n_cus;
   float* d_slabs;       // partial-sum slabs of chunked renders, grown on demand
   size_t slab_floats;
@@ -2870,6 +2870,38 @@ int launch_render(rt_ctx* ctx, const rt_camera* cam, const rt_render_params* p, 
   const DevCamera dc = to_dev_camera(cam);
   const int n_items = n_tiles * A.n_chunks;
   const dim3 block(64);
+  // One wave for every slot a CU has (8 per SIMD); where the kernel's registers allow fewer, the rest
+  // start when the first waves are done, find no item left and leave.  Never more waves than items.
+  long long waves = 32LL * (ctx->n_cus > 0 ? ctx->n_cus : 1);
+  if (waves > n_items) waves = n_items;
+  // The stack kernel keeps the first entries of a lane's stack in LDS (what decides how many waves a CU holds) and
+  // the rest of the scene's worst case in global memory, one region per wave of the grid.
+  A.stack_lds = 0;
+  A.stack_ovf = nullptr;
+  if (trav == TRAV_STACK) {
+    int cap = RT_STACK_LDS_RENDER;
+    if (const char* e = getenv("RT_STACK_LDS_CAP")) cap = atoi(e) > 0 ? atoi(e) : cap;  // tuning
+    A.stack_lds = ctx->dev.stack_depth < cap ? ctx->dev.stack_depth : cap;
+    const size_t ovf_bytes = (size_t)waves * (size_t)(ctx->dev.stack_depth - A.stack_lds) * 64 * sizeof(unsigned);
+    if (ovf_bytes > 0 && no_alloc) {
+      // after the counter, and after the partial images of a launch that has them
+      size_t at = RT_NOALLOC_SLAB_OFFSET;
+      if (!A.accumulate && A.n_chunks > 1) at += (size_t)A.n_chunks * per_image * sizeof(float);
+      at = (at + 255) & ~(size_t)255;
+      if (at + ovf_bytes > RT_NOALLOC_SCRATCH_BYTES)
+        return rt::set_error(RT_ERR_UNSUPPORTED, "rt_render_device_noalloc: the static scratch cannot hold this launch's partial images and stack overflow region");
+      A.stack_ovf = (unsigned*)(ctx->scratch_ptr + at);
+    } else if (ovf_bytes > 0) {
+      if (ovf_bytes > ctx->stack_ovf_bytes) {
+        if (ctx->d_stack_ovf) HIP_TRY(hipFree(ctx->d_stack_ovf));
+        ctx->d_stack_ovf = nullptr;
+        ctx->stack_ovf_bytes = 0;
+        HIP_TRY(hipMalloc((void**)&ctx->d_stack_ovf, ovf_bytes));
+        ctx->stack_ovf_bytes = ovf_bytes;
+      }
+      A.stack_ovf = ctx->d_stack_ovf;
+    }
+  }
   typedef void (*RenderFn)(DevScene, DevCamera, RenderArgs, float*, float*, unsigned long long*, unsigned*);
 #define RT_TRIO(ST, SQ, TR) render_kernel<ST, SQ, TR, 0>, render_kernel<ST, SQ, TR, 1>, render_kernel<ST, SQ, TR, 2>, render_kernel<ST, SQ, TR, 3>
 #define RT_ROW(ST, SQ) RT_TRIO(ST, SQ, TRAV_SCAN), RT_TRIO(ST, SQ, TRAV_FLAT), nullptr, nullptr, nullptr, nullptr  /* stack scenes: render_stack_kernel */
@@ -2883,12 +2915,8 @@ int launch_render(rt_ctx* ctx, const rt_camera* cam, const rt_render_params* p, 
   // scenes on the per-lane stack traversal: the kernel that keeps a lane's traversal going across the shading code
   if (trav == TRAV_STACK) fn = stack_table[(stats ? 8 : 0) + (d_sumsq ? 4 : 0) + ctx->general];
   size_t lds_bytes = trav == TRAV_FLAT ? (size_t)ctx->dev.n_dprims * 6 * sizeof(float4) : 0;
-  if (trav == TRAV_STACK) lds_bytes = (size_t)ctx->dev.stack_lds * 64 * sizeof(unsigned);
+  if (trav == TRAV_STACK) lds_bytes = (size_t)A.stack_lds * 64 * sizeof(unsigned);
 
-  // One wave for every slot a CU has (8 per SIMD); where the kernel's registers allow fewer, the rest
-  // start when the first waves are done, find no item left and leave.  Never more waves than items.
-  long long waves = 32LL * (ctx->n_cus > 0 ? ctx->n_cus : 1);
-  if (waves > n_items) waves = n_items;
   // All launches of a context share its counter and slabs (and all no_alloc launches on a device share `scratch`):
   // a launch on another stream than the last one first waits for that one to finish.
   if (ctx->launched && ctx->last_stream != stream) HIP_TRY(hipStreamWaitEvent(stream, ctx->ev_launch, 0));
@@ -2984,6 +3012,7 @@ int rt_destroy(rt_ctx* ctx) {
   free_scene(ctx);
   if (ctx->d_stats) (void)hipFree(ctx->d_stats);
   if (ctx->d_queue) (void)hipFree(ctx->d_queue);
+  if (ctx->d_stack_ovf) (void)hipFree(ctx->d_stack_ovf);
   if (ctx->d_slabs) (void)hipFree(ctx->d_slabs);
   for (int k = 0; k < 6; ++k)
     if (ctx->d_stage[k]) (void)hipFree(ctx->d_stage[k]);
@@ -3028,7 +3057,7 @@ int rt_upload_scene(rt_ctx* ctx, const rt_scene* s) {
   std::vector<float> box6_recs;
   if (want_stack) {
     root_ref = W.ref_of(TB.build_under(0), &stack_need);
-    if (stack_need + 2 > RT_STACK_LDS + RT_STACK_PRIVATE) {
+    if (stack_need + 2 > RT_STACK_MAX) {
       // the heuristic's tree is too deep for a lane's stack: the balanced one over the same leaves
       TB.nodes.clear();
       TB.halve_only = true;
@@ -3056,7 +3085,7 @@ int rt_upload_scene(rt_ctx* ctx, const rt_scene* s) {
       if (s->objects[i].kind == RT_OBJ_LIST) note_box6(s->objects[i].first, s->objects[i].count);
   }
   // a tree whose walk could need more stack than a lane has (LDS part + private part) takes the scan
-  const bool stack_mode = want_stack && stack_need + 2 <= RT_STACK_LDS + RT_STACK_PRIVATE;
+  const bool stack_mode = want_stack && stack_need + 2 <= RT_STACK_MAX;
   std::vector<BNode> bnodes;
   std::vector<int> prim_rank((size_t)s->n_prims, 0);
   std::vector<ScanNode> media_scan;
@@ -3149,7 +3178,7 @@ int rt_upload_scene(rt_ctx* ctx, const rt_scene* s) {
   d.objects = (const rt_object*)ctx->d_objects;
   d.stack_mode = stack_mode ? 1 : 0;
   d.stack_depth = stack_mode ? stack_need + 2 : 0;  // what the deepest walk can have in use, and a margin
-  d.stack_lds = d.stack_depth < RT_STACK_LDS ? d.stack_depth : RT_STACK_LDS;
+  d.stack_lds = d.stack_depth;  // (the trace kernel's; the render kernel's LDS part is set per launch)
   if (getenv("RT_VERBOSE"))
     std::fprintf(stderr, "rt_upload_scene: %d nodes, %d primitives, reference tree depth %d; traversal %s; four-wide entries %zu, stack entries per lane %d (%s tree)\n",
                  s->n_nodes, s->n_prims, depth, stack_mode ? "stack" : (d.flat ? "flat" : "scan"), W.out.size(), d.stack_depth,
