@@ -218,14 +218,7 @@ typedef struct rt_render_params {
  * that the tiles t = shard_index (mod shard_count) of one shard never line up in
  * columns; numbers whose column lies beyond the image's edge stand for no tile.
  * Tile t covers pixels x in [8*(t % w), +8), y in [8*(t / w), +8) (y from the top). */
-static inline int rt_shard_width(int nx, int shard_count) {
-  int w = (nx + 7) / 8;
-  for (;; ++w) {
-    int a = w, b = shard_count > 0 ? shard_count : 1;
-    while (b) { const int r = a % b; a = b; b = r; }
-    if (a == 1 || shard_count <= 1) return w;
-  }
-}
+int rt_shard_width(int nx, int shard_count);
 
 /* Random numbers.  The reference draws everything from rand::thread_rng()
  * (OS seeded, not replayable).  This ABI fixes a counter-based stream instead:

@@ -798,13 +798,24 @@ template <class R> inline V3<R> de_nan(V3<R> c) {
   return c;
 }
 
+// rt_shard_width of include/rt_abi.h, restated (the oracle does not link the library it checks).
+static int shard_grid_width(int nx, int shard_count) {
+  int w = (nx + 7) / 8;
+  if (shard_count <= 1) return w;
+  for (;; ++w) {
+    int a = w, b = shard_count;
+    while (b) { const int r = a % b; a = b; b = r; }
+    if (a == 1) return w;
+  }
+}
+
 template <class P>
 void render_rows(const rt_scene* scene, const rt_camera* cam, const rt_render_params* prm, int j_begin, int j_end,
                  int sample_begin, int sample_end, double* sum, double* sumsq, Counters* counters) {
   typedef typename P::Real R;
   World<P> world(scene);
   const int nx = prm->nx, ny = prm->ny;
-  const int shard_width = rt_shard_width(nx, prm->shard_count);
+  const int shard_width = shard_grid_width(nx, prm->shard_count);
   // main.rs:96-116
   for (int j = j_end - 1; j >= j_begin; --j) {
     for (int i = 0; i < nx; ++i) {

@@ -3006,6 +3006,16 @@ int rt_create(int device_id, rt_ctx** out) {
   return RT_OK;
 }
 
+int rt_shard_width(int nx, int shard_count) {
+  int w = (nx + 7) / 8;
+  if (shard_count <= 1) return w;
+  for (;; ++w) {
+    int a = w, b = shard_count;
+    while (b) { const int r = a % b; a = b; b = r; }
+    if (a == 1) return w;
+  }
+}
+
 int rt_destroy(rt_ctx* ctx) {
   if (!ctx) return RT_OK;
   (void)hipSetDevice(ctx->device);
