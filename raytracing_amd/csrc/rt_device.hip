@@ -1663,7 +1663,9 @@ __global__ void __launch_bounds__(64, (TRAV == TRAV_STACK && GENERAL < 2) ? 6 : 
 #define RT_READY_LANES 48
 #endif
 #ifndef RT_SLOTS
-#define RT_SLOTS 2
+// (scenes with media or the older materials have paths of depth 50 beside paths of depth 3: a third open item keeps
+// the lanes fed while two items wait for their last paths: final scene -5 %; the Lambertian build gains nothing from it)
+#define RT_SLOTS (GENERAL >= 1 ? 3 : 2)
 #endif
 #ifndef RT_STACK_LAST_SPP
 #define RT_STACK_LAST_SPP 4  // render_stack_kernel: the last sample chunk of a tile is halved down to parts of this many samples
