@@ -358,9 +358,9 @@ __device__ __forceinline__ bool slab_core(float x0, float y0, float z0, float x1
   const float nz = sg.z ? t1 : t0;
   t_min = fmaxf(nz, t_min);
   t_max = fminf(sg.z ? t0 : t1, t_max);
-  t_enter = t_min;
   const float ny_top = sg.y ? (y_top - r.o.y) * r.inv.y : ny;
   const float t_prune = fmaxf(fmaxf(nx, nz), fmaxf(ny_top, t_min0));
+  t_enter = t_prune;  // the distance below which nothing under this box can be hit (not negative: t_min0 is not)
   // Not in the reference, which works in f64: a rect's box is 0.0002 thick, and from an origin a few thousand
   // units away (bound - origin) rounds to the same float for both faces, so the entry and exit distances are
   // equal and bvh.rs:58's `<=` rejects a box the ray goes through.  The exit distance is widened by two units
@@ -373,7 +373,7 @@ __device__ __forceinline__ bool slab_box(float x0, float y0, float z0, float x1,
   float te;
   return slab_core(x0, y0, z0, x1, y1, z1, y1, r, sg, t_min, t_max, 3.402823466e+38f, te);
 }
-// The same with pruning against best_t, also handing back where the ray enters the box (meaningful when it does).
+// The same with pruning against best_t, also handing back the pruning distance (where the ray enters the box raised to y_top).
 __device__ __forceinline__ bool slab_box_enter(float4 lo, float4 hi, float y_top, const RayF& r, const Signs& sg, float t_min, float t_max,
                                                float best_t, float& t_enter) {
   return slab_core(lo.x, lo.y, lo.z, hi.x, hi.y, hi.z, y_top, r, sg, t_min, t_max, best_t, t_enter);
@@ -734,18 +734,19 @@ __device__ __forceinline__ void leaf_list_lane(const DevScene& S, int first, int
 // gets that deep.  The trace kernel keeps the whole stack in LDS (n_lds = the scene's depth, ovf unused).
 #define RT_STACK_MAX 64  // deepest walk the stack traversal takes (LDS + overflow)
 #ifndef RT_STACK_LDS_RENDER
-#define RT_STACK_LDS_RENDER 12  // entries the render kernel keeps in LDS
+#define RT_STACK_LDS_RENDER 10  // entries (of two dwords) the render kernel keeps in LDS
 #endif
 template <bool OVF>
 struct LaneStackT {
-  unsigned* lds;  // this lane's column
+  unsigned* lds;  // this lane's column: entry `at` is the pair lds[at * 128] (reference), lds[at * 128 + 64] (distance key)
   int n_lds;      // entries in LDS
-  unsigned* ovf;  // this lane's column of the wave's overflow region (OVF only)
-  __device__ __forceinline__ void put(int at, unsigned v) {
-    if (!OVF || at < n_lds) lds[at * 64] = v;
-    else ovf[(at - n_lds) * 64] = v;
+  unsigned* ovf;  // this lane's column of the wave's overflow region, same layout (OVF only)
+  __device__ __forceinline__ void put(int at, unsigned ref, unsigned key) {
+    if (!OVF || at < n_lds) { lds[at * 128] = ref; lds[at * 128 + 64] = key; }
+    else { ovf[(at - n_lds) * 128] = ref; ovf[(at - n_lds) * 128 + 64] = key; }
   }
-  __device__ __forceinline__ unsigned get(int at) const { return (!OVF || at < n_lds) ? lds[at * 64] : ovf[(at - n_lds) * 64]; }
+  __device__ __forceinline__ unsigned get(int at) const { return (!OVF || at < n_lds) ? lds[at * 128] : ovf[(at - n_lds) * 128]; }
+  __device__ __forceinline__ unsigned get_key(int at) const { return (!OVF || at < n_lds) ? lds[at * 128 + 64] : ovf[(at - n_lds) * 128 + 64]; }
 };
 
 // The state of one lane's walk through the four-wide tree.
@@ -778,13 +779,20 @@ __device__ __forceinline__ int trav_enter(const DevScene& S, int ref, int box, c
 template <bool STATS, class STK>
 __device__ __forceinline__ bool trav_step(const DevScene& S, STK& stk, Trav& T, const RayF& w, float t_min, float t_max, Counters& cnt) {
   if (T.cur == TRAV_POP) {
+    // Entries wait on the stack with their pruning distance (the sort key of the step that pushed them: the distance
+    // rounded down by its two lowest bits): what has been found since may lie nearer than an entry's box begins,
+    // and then the entry goes without a fetch.  (An exact tie cannot hide in it: every hit under the box is farther.)
     if (T.sp == 0) return false;
     --T.sp;
     const unsigned x = stk.get(T.sp);
+    const unsigned key = stk.get_key(T.sp);
     if (x == STACK_RESTORE) {
       T.r = w;
       return true;
     }
+    // (no loop: a lane whose entry is pruned pops the next one in its next trip; looping here, or looking at two
+    // entries at once, was measured slower)
+    if (__uint_as_float(key & ~3u) > T.best.t) return true;
     T.cur = (int)x;
   }
   const int cur = T.cur;
@@ -815,9 +823,9 @@ __device__ __forceinline__ bool trav_step(const DevScene& S, STK& stk, Trav& T, 
   lo_ = min(k1, k2); hi_ = max(k1, k2); k1 = lo_; k2 = hi_;
   const int n_hit = (int)h0 + (int)h1 + (int)h2 + (int)h3;
 #define RT_REF_OF(k) (((k) & 2u) ? (((k) & 1u) ? r3 : r2) : (((k) & 1u) ? r1 : r0))
-  if (n_hit >= 4) { stk.put(T.sp, (unsigned)RT_REF_OF(k3)); ++T.sp; }
-  if (n_hit >= 3) { stk.put(T.sp, (unsigned)RT_REF_OF(k2)); ++T.sp; }
-  if (n_hit >= 2) { stk.put(T.sp, (unsigned)RT_REF_OF(k1)); ++T.sp; }
+  if (n_hit >= 4) { stk.put(T.sp, (unsigned)RT_REF_OF(k3), k3); ++T.sp; }
+  if (n_hit >= 3) { stk.put(T.sp, (unsigned)RT_REF_OF(k2), k2); ++T.sp; }
+  if (n_hit >= 2) { stk.put(T.sp, (unsigned)RT_REF_OF(k1), k1); ++T.sp; }
   T.cur = n_hit >= 1 ? RT_REF_OF(k0) : TRAV_POP;
 #undef RT_REF_OF
   return true;
@@ -848,7 +856,7 @@ __device__ __forceinline__ void trav_leaf(const DevScene& S, STK& stk, Trav& T, 
   if (ob.kind == RT_OBJ_LIST) {
     leaf_list_lane<STATS>(S, ob.first, ob.count, q, t_min, t_max, T.best, cnt);
   } else {
-    stk.put(T.sp, STACK_RESTORE);
+    stk.put(T.sp, STACK_RESTORE, 0u);
     ++T.sp;
     T.r = q;
     T.cur = trav_enter<STATS>(S, S.sub_root_ref[ref], ob.first, T.r, t_min, t_max, cnt);
@@ -971,8 +979,8 @@ template <int TRAV>
 __global__ void __launch_bounds__(256) trace_kernel(DevScene S, const float* __restrict__ o, const float* __restrict__ d, size_t n,
                                                     float t_min, float t_max, int* __restrict__ prim_id, float* __restrict__ t_out,
                                                     float* __restrict__ normal, float* __restrict__ p_out) {
-  extern __shared__ unsigned trace_stack_lds[];  // TRAV_STACK: stack_lds entries of 64 lanes for each of the 4 waves
-  unsigned* stk = trace_stack_lds + (TRAV == TRAV_STACK ? (threadIdx.x >> 6) * S.stack_lds * 64 : 0) + (threadIdx.x & 63);
+  extern __shared__ unsigned trace_stack_lds[];  // TRAV_STACK: stack_lds entries (two dwords) of 64 lanes for each of the 4 waves
+  unsigned* stk = trace_stack_lds + (TRAV == TRAV_STACK ? (threadIdx.x >> 6) * S.stack_lds * 128 : 0) + (threadIdx.x & 63);
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   // Whole waves stay in the loop together: the traversal uses wave-wide operations.
   const size_t n_round = (n + 63) / 64 * 64;
@@ -1347,7 +1355,7 @@ struct RenderArgs {
   int hold_lanes;           // and lanes holding a leaf (in 64 traversing ones) that make the wave run the leaf code
   int accumulate;           // render_stack_kernel: items ADD their tile sums to the (zeroed) output instead of writing partial images
   int stack_lds;            // render_stack_kernel: entries of a lane's stack kept in LDS; deeper ones go to stack_ovf
-  unsigned* stack_ovf;      // (scene's stack depth - stack_lds) x 64 dwords for every wave of the grid
+  unsigned* stack_ovf;      // (scene's stack depth - stack_lds) x 128 dwords for every wave of the grid
 };
 
 // Waves per SIMD the register allocator must leave room for (launch_bounds' second argument).
@@ -1696,7 +1704,7 @@ __global__ void __launch_bounds__(64, GENERAL < 2 ? RT_STACK_WAVES : 5) render_s
   LaneStackT<true> stk;
   stk.lds = (unsigned*)prim_lds + (threadIdx.x & 63);
   stk.n_lds = A.stack_lds;
-  stk.ovf = A.stack_ovf + (size_t)blockIdx.x * (size_t)(S.stack_depth - A.stack_lds) * 64 + (threadIdx.x & 63);
+  stk.ovf = A.stack_ovf + (size_t)blockIdx.x * (size_t)(S.stack_depth - A.stack_lds) * 128 + (threadIdx.x & 63);
   const int lane = threadIdx.x & 63;
   __shared__ float cam_lds[20];
   if (lane == 0) {
@@ -2884,7 +2892,7 @@ int launch_render(rt_ctx* ctx, const rt_camera* cam, const rt_render_params* p, 
     int cap = RT_STACK_LDS_RENDER;
     if (const char* e = getenv("RT_STACK_LDS_CAP")) cap = atoi(e) > 0 ? atoi(e) : cap;  // tuning
     A.stack_lds = ctx->dev.stack_depth < cap ? ctx->dev.stack_depth : cap;
-    const size_t ovf_bytes = (size_t)waves * (size_t)(ctx->dev.stack_depth - A.stack_lds) * 64 * sizeof(unsigned);
+    const size_t ovf_bytes = (size_t)waves * (size_t)(ctx->dev.stack_depth - A.stack_lds) * 128 * sizeof(unsigned);
     if (ovf_bytes > 0 && no_alloc) {
       // after the counter, and after the partial images of a launch that has them
       size_t at = RT_NOALLOC_SLAB_OFFSET;
@@ -2917,7 +2925,7 @@ int launch_render(rt_ctx* ctx, const rt_camera* cam, const rt_render_params* p, 
   // scenes on the per-lane stack traversal: the kernel that keeps a lane's traversal going across the shading code
   if (trav == TRAV_STACK) fn = stack_table[(stats ? 8 : 0) + (d_sumsq ? 4 : 0) + ctx->general];
   size_t lds_bytes = trav == TRAV_FLAT ? (size_t)ctx->dev.n_dprims * 6 * sizeof(float4) : 0;
-  if (trav == TRAV_STACK) lds_bytes = (size_t)A.stack_lds * 64 * sizeof(unsigned);
+  if (trav == TRAV_STACK) lds_bytes = (size_t)A.stack_lds * 128 * sizeof(unsigned);
 
   // All launches of a context share its counter and slabs (and all no_alloc launches on a device share `scratch`):
   // a launch on another stream than the last one first waits for that one to finish.
@@ -3308,7 +3316,15 @@ int rt_trace_closest(rt_ctx* ctx, const float* o, const float* d, size_t n, floa
   if (e == hipSuccess) {
     size_t blocks = (n + 255) / 256;
     if (blocks > 4096) blocks = 4096;
-    if (ctx->dev.stack_mode) hipLaunchKernelGGL(trace_kernel<TRAV_STACK>, dim3((unsigned)blocks), dim3(256), (size_t)ctx->dev.stack_lds * 4 * 64 * sizeof(unsigned), 0, ctx->dev, d_o, d_d, n, t_min, t_max, d_id, d_t, d_n, d_p);
+    if (ctx->dev.stack_mode) {
+      // the whole stack of every lane in LDS: as many waves per workgroup (at most 4) as 64 KB hold
+      const size_t per_wave = (size_t)ctx->dev.stack_lds * 128 * sizeof(unsigned);
+      int wpb = per_wave ? (int)(65536 / per_wave) : 4;
+      wpb = wpb > 4 ? 4 : (wpb < 1 ? 1 : wpb);
+      size_t sblocks = (n + (size_t)wpb * 64 - 1) / ((size_t)wpb * 64);
+      if (sblocks > 16384u / (unsigned)wpb) sblocks = 16384u / (unsigned)wpb;
+      hipLaunchKernelGGL(trace_kernel<TRAV_STACK>, dim3((unsigned)sblocks), dim3((unsigned)wpb * 64), per_wave * (size_t)wpb, 0, ctx->dev, d_o, d_d, n, t_min, t_max, d_id, d_t, d_n, d_p);
+    }
     else if (ctx->dev.flat) hipLaunchKernelGGL(trace_kernel<TRAV_FLAT>, dim3((unsigned)blocks), dim3(256), 0, 0, ctx->dev, d_o, d_d, n, t_min, t_max, d_id, d_t, d_n, d_p);
     else hipLaunchKernelGGL(trace_kernel<TRAV_SCAN>, dim3((unsigned)blocks), dim3(256), 0, 0, ctx->dev, d_o, d_d, n, t_min, t_max, d_id, d_t, d_n, d_p);
     e = hipGetLastError();
