@@ -298,7 +298,9 @@ int rt_render_device(rt_ctx* ctx, const rt_camera* cam, const rt_render_params* 
  * 100 spp (5 partial images, 63 MB); 1024x1024 at 1000 spp does not (15 partial
  * images, 189 MB); any image at fewer than 64 spp does (one chunk, no partial
  * images), and so does any launch of a scene on the per-lane stack traversal (it
- * has no partial images; see rt_render_device for what that means for its bits).
+ * has no partial images; see rt_render_device for what that means for its bits;
+ * the deep ends of its lanes' traversal stacks live in the scratch too, and what
+ * of them does not fit stays in LDS, which costs speed, not the launch).
  * Every call on a GPU, from any context, uses that GPU's one array: calls that
  * overlap on one GPU race (calls of one context are ordered as for
  * rt_render_device; calls of different contexts on one device are the caller's

@@ -2898,8 +2898,12 @@ int launch_render(rt_ctx* ctx, const rt_camera* cam, const rt_render_params* p, 
       size_t at = RT_NOALLOC_SLAB_OFFSET;
       if (!A.accumulate && A.n_chunks > 1) at += (size_t)A.n_chunks * per_image * sizeof(float);
       at = (at + 255) & ~(size_t)255;
-      if (at + ovf_bytes > RT_NOALLOC_SCRATCH_BYTES)
-        return rt::set_error(RT_ERR_UNSUPPORTED, "rt_render_device_noalloc: the static scratch cannot hold this launch's partial images and stack overflow region");
+      if (at > RT_NOALLOC_SCRATCH_BYTES)
+        return rt::set_error(RT_ERR_UNSUPPORTED, "rt_render_device_noalloc: the static scratch cannot hold this launch's partial images");
+      // what does not fit the scratch stays in LDS (fewer waves per CU: slower, not refused)
+      const size_t per_entry = (size_t)waves * 128 * sizeof(unsigned);
+      const int fit = (int)((RT_NOALLOC_SCRATCH_BYTES - at) / per_entry);
+      if (ctx->dev.stack_depth - A.stack_lds > fit) A.stack_lds = ctx->dev.stack_depth - fit;
       A.stack_ovf = (unsigned*)(ctx->scratch_ptr + at);
     } else if (ovf_bytes > 0) {
       if (ovf_bytes > ctx->stack_ovf_bytes) {

@@ -63,3 +63,20 @@ def test_noalloc_refuses_a_launch_beyond_its_scratch(gpu, hipmem, cornell):
     # at 100 spp the same image fits (5 partial images, 63 MB)
     (ref, _), (got, _) = _both(gpu, hipmem, cornell.camera, make_params(1024, 1024, 100))
     assert np.array_equal(ref, got)
+
+
+def test_noalloc_on_a_tree_scene(gpu, hipmem):
+    """A scene on the per-lane stack traversal: no partial images (its work items add
+    into the output), and the deep end of the lanes' stacks lives in the scratch too.
+    Such a scene's sums depend on scheduling in their last bits, hence the tolerance."""
+    from raytracing_amd import Scene, make_params
+    from test_gpu_materials import _sphere_field
+    with Scene(77) as sc:
+        cam, world = _sphere_field(300, 3, glass_and_metal=True)
+        sc.light_xz_rect(-3.0, 3.0, -3.0, 3.0, 6.0)
+        flat = sc.flatten(world)
+    gpu.upload_scene(flat)
+    for p in (make_params(160, 96, 200, seed=8), make_params(64, 40, 20, seed=9)):
+        (ref, _), (got, _) = _both(gpu, hipmem, cam, p)
+        assert np.isfinite(ref).all() and ref.sum() > 0
+        assert np.allclose(ref, got, rtol=1e-5, atol=1e-4)
