@@ -2,5 +2,5 @@
 # Sweep of the share of traversing lanes that must hold a leaf before the wave runs the leaf code (run through gpurun).
 for n in ${SWEEP:-64 48 32 16}; do
   echo "RT_HOLD_LANES=$n"
-  RT_HOLD_LANES=$n VARIANTS=0 bash tools/stack_ab.sh | grep -v kernel || exit 1
+  RT_HOLD_LANES=$n bash tools/stack_ab.sh || exit 1
 done
