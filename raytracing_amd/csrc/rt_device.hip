@@ -777,7 +777,7 @@ __device__ __forceinline__ int trav_enter(const DevScene& S, int ref, int box, c
 // when the walk has ended.  (Leaves, single primitives included, are left to trav_leaf: the wave runs that code for
 // many lanes at once, which was measured faster than testing a primitive where a lane meets it.)
 template <bool STATS, class STK>
-__device__ __forceinline__ bool trav_step(const DevScene& S, STK& stk, Trav& T, const RayF& w, float t_min, float t_max, Counters& cnt) {
+__device__ __forceinline__ bool trav_step(const DevScene& S, STK& stk, Trav& T, float t_min, float t_max, Counters& cnt) {
   if (T.cur == TRAV_POP) {
     // Entries wait on the stack with their pruning distance (the sort key of the step that pushed them: the distance
     // rounded down by its two lowest bits): what has been found since may lie nearer than an entry's box begins,
@@ -787,7 +787,11 @@ __device__ __forceinline__ bool trav_step(const DevScene& S, STK& stk, Trav& T, 
     const unsigned x = stk.get(T.sp);
     const unsigned key = stk.get_key(T.sp);
     if (x == STACK_RESTORE) {
-      T.r = w;
+      // back in the world frame: the world ray waits under the marker (trav_leaf put it there), its reciprocals are made again
+      const F3 wo = f3(__uint_as_float(stk.get(T.sp - 3)), __uint_as_float(stk.get(T.sp - 2)), __uint_as_float(stk.get(T.sp - 1)));
+      const F3 wd = f3(__uint_as_float(stk.get_key(T.sp - 3)), __uint_as_float(stk.get_key(T.sp - 2)), __uint_as_float(stk.get_key(T.sp - 1)));
+      T.sp -= 3;
+      T.r = make_ray(wo, wd);
       return true;
     }
     // (no loop: a lane whose entry is pruned pops the next one in its next trip; looping here, or looking at two
@@ -835,7 +839,7 @@ __device__ __forceinline__ bool trav_step(const DevScene& S, STK& stk, Trav& T, 
 // Translate/RotateY over a list or over a BvhNode, whose sub-tree the lane enters in the object's frame with a
 // marker on the stack that switches it back.  ConstantMedium leaves are left to the caller (they draw random numbers).
 template <bool STATS, class STK>
-__device__ __forceinline__ void trav_leaf(const DevScene& S, STK& stk, Trav& T, const RayF& w, float t_min, float t_max, Counters& cnt) {
+__device__ __forceinline__ void trav_leaf(const DevScene& S, STK& stk, Trav& T, float t_min, float t_max, Counters& cnt) {
   const int node = T.cur & BN_INDEX_MASK;
   const bool single = (T.cur & BN2_PRIM) != 0;
   T.cur = TRAV_POP;
@@ -851,13 +855,19 @@ __device__ __forceinline__ void trav_leaf(const DevScene& S, STK& stk, Trav& T, 
   }
   const rt_object ob = S.objects[ref];
   if (ob.kind == RT_OBJ_MEDIUM) return;
-  const RayF q = to_object_frame<true>(w, ob.xform, ob.sin_theta, ob.cos_theta, ob.offset[0], ob.offset[1], ob.offset[2]);
+  // (objects are leaves of the world tree only, so the lane is in the world frame here: T.r is the world ray)
+  const RayF q = to_object_frame<true>(T.r, ob.xform, ob.sin_theta, ob.cos_theta, ob.offset[0], ob.offset[1], ob.offset[2]);
   if (STATS) cnt.instance_ops++;
   if (ob.kind == RT_OBJ_LIST) {
     leaf_list_lane<STATS>(S, ob.first, ob.count, q, t_min, t_max, T.best, cnt);
   } else {
-    stk.put(T.sp, STACK_RESTORE, 0u);
-    ++T.sp;
+    // the lane keeps one ray, the one of the frame it is in: the world ray goes on the stack (three entries: a
+    // component of the origin where a reference would be, of the direction where its key would be) under the marker
+    stk.put(T.sp, __float_as_uint(T.r.o.x), __float_as_uint(T.r.d.x));
+    stk.put(T.sp + 1, __float_as_uint(T.r.o.y), __float_as_uint(T.r.d.y));
+    stk.put(T.sp + 2, __float_as_uint(T.r.o.z), __float_as_uint(T.r.d.z));
+    stk.put(T.sp + 3, STACK_RESTORE, 0u);
+    T.sp += 4;
     T.r = q;
     T.cur = trav_enter<STATS>(S, S.sub_root_ref[ref], ob.first, T.r, t_min, t_max, cnt);
   }
@@ -885,9 +895,9 @@ __device__ __forceinline__ void trace_stack(const DevScene& S, unsigned* __restr
     // down until this lane holds a list or instance leaf (lanes that have one wait for the rest of the wave,
     // so the leaf code runs once for many lanes instead of once per step)
     bool more = true;
-    while (more && !trav_holds_leaf(T.cur)) more = trav_step<STATS>(S, stk, T, w, t_min, t_max, cnt);
+    while (more && !trav_holds_leaf(T.cur)) more = trav_step<STATS>(S, stk, T, t_min, t_max, cnt);
     if (!more) break;
-    trav_leaf<STATS>(S, stk, T, w, t_min, t_max, cnt);
+    trav_leaf<STATS>(S, stk, T, t_min, t_max, cnt);
   }
   best = T.best;
 }
@@ -1679,7 +1689,7 @@ __global__ void __launch_bounds__(64, (TRAV == TRAV_STACK && GENERAL < 2) ? 6 : 
 #define RT_STACK_LAST_SPP 4  // render_stack_kernel: the last sample chunk of a tile is halved down to parts of this many samples
 #endif
 #ifndef RT_STACK_WAVES
-#define RT_STACK_WAVES 5  // waves per SIMD the register allocator leaves room for in the builds without textures
+#define RT_STACK_WAVES 6  // waves per SIMD the register allocator leaves room for in the builds without textures (80 registers: no spills)
 #endif
 // Diagnostic build (-DRT_PHASE_TIMING): shader-clock stamps around the parts of the loop, summed per wave into
 // stats[16..31] by the counting build and printed by rt_render.  No stamp exists in the normal build.
@@ -1744,15 +1754,18 @@ __global__ void __launch_bounds__(64, GENERAL < 2 ? RT_STACK_WAVES : 5) render_s
   // Per-lane path state.
   bool alive = false;  // on a path
   bool trav = false;   // in a traversal (implies alive)
-  F3 ro = f3(0, 0, 0), rd = f3(0, 0, 1);  // the ray of the current segment, world frame
   F3 thr = f3(0, 0, 0);
   int depth = 0, pix = 0;  // pix: slot * 64 + pixel within the tile
   unsigned pixel_id = 0, sample = 0;
   int pend = -1;
-  // Per-lane traversal state.
-  RayF wr = make_ray(ro, rd);  // the world ray with its reciprocals
+  // Per-lane traversal state.  A lane keeps ONE ray, T.r: the world ray of the segment it shades or traverses, or,
+  // while it is inside an object's sub-tree, that ray in the object's frame (the world ray then waits on the lane's
+  // stack, see trav_leaf).  A walk that has ended is back in the world frame.
   Trav T;
-  T.r = wr;
+  T.r = make_ray(f3(0, 0, 0), f3(0, 0, 1));
+  F3& ro = T.r.o;  // (the names the shading code uses)
+  F3& rd = T.r.d;
+#define RT_WORLD_RAY() (T.r)
   T.sp = 0;
   T.cur = TRAV_POP;
   T.best.t = INFINITY;
@@ -1795,11 +1808,11 @@ __global__ void __launch_bounds__(64, GENERAL < 2 ? RT_STACK_WAVES : 5) render_s
       // what is left of world.hit: the ConstantMedium nodes (they draw random numbers)
       if (GENERAL != 0 && S.n_scan > 0) {
         const PathRng rng = {pixel_id, sample, (unsigned)depth, key0, key1};
-        scan_range<STATS, true, true, 0>(S, 0, S.n_scan, act, wr, a_t_min, INFINITY, rng, T.best, cnt);
+        scan_range<STATS, true, true, 0>(S, 0, S.n_scan, act, RT_WORLD_RAY(), a_t_min, INFINITY, rng, T.best, cnt);
       }
       RT_STAMP(1);  // media
       const U4 w = philox4x32_10(pixel_id, sample, (unsigned)depth, 0u, key0, key1);
-      const Shaded sh = shade_vertex<STATS, GENERAL>(S, dprim_tab, act, T.best, wr, thr, depth, w, a_max_depth, a_sky, pixel_id, sample, key0, key1, cnt);
+      const Shaded sh = shade_vertex<STATS, GENERAL>(S, dprim_tab, act, T.best, RT_WORLD_RAY(), thr, depth, w, a_max_depth, a_sky, pixel_id, sample, key0, key1, cnt);
       RT_STAMP(2);  // philox + shade
       const bool go_on = act & sh.scattered & ((sh.thr_next.x > 0.0f) | (sh.thr_next.y > 0.0f) | (sh.thr_next.z > 0.0f));
       const bool done = act & !go_on;
@@ -1996,8 +2009,7 @@ __global__ void __launch_bounds__(64, GENERAL < 2 ? RT_STACK_WAVES : 5) render_s
       memset(&c2, 0, sizeof(c2));
       const int first = trav_enter<STATS>(S, S.root_ref, 0, nr, a_t_min, INFINITY, c2);
       if (STATS) cnt.node_tests += go;
-      wr.o = sel3(go, nr.o, wr.o); wr.d = sel3(go, nr.d, wr.d); wr.inv = sel3(go, nr.inv, wr.inv);
-      T.r.o = sel3(go, nr.o, T.r.o); T.r.d = sel3(go, nr.d, T.r.d); T.r.inv = sel3(go, nr.inv, T.r.inv);
+      T.r.inv = sel3(go, nr.inv, T.r.inv);
       T.cur = go ? first : T.cur;
       T.sp = go ? 0 : T.sp;
       T.best.t = go ? INFINITY : T.best.t;
@@ -2009,14 +2021,14 @@ __global__ void __launch_bounds__(64, GENERAL < 2 ? RT_STACK_WAVES : 5) render_s
     for (;;) {
       RT_COUNT(10, 1); RT_COUNT(11, __popcll(__ballot(trav)));
       // one step for every lane that has one to make; a lane holding a list or instance leaf waits for the leaf code below
-      if (trav & !trav_holds_leaf(T.cur)) trav = trav_step<STATS>(S, stk, T, wr, a_t_min, INFINITY, cnt);
+      if (trav & !trav_holds_leaf(T.cur)) trav = trav_step<STATS>(S, stk, T, a_t_min, INFINITY, cnt);
       RT_STAMP(6);  // step
       const bool hold = trav & trav_holds_leaf(T.cur);
       const unsigned long long m_trav = __ballot(trav), m_hold = __ballot(hold);
       // the leaf code runs once for all lanes that hold a leaf, when enough of the traversing lanes do
       if (m_hold != 0ull && __popcll(m_hold) * 64 >= a_hold * __popcll(m_trav)) {
         RT_COUNT(12, 1); RT_COUNT(13, __popcll(m_hold));
-        if (hold) trav_leaf<STATS>(S, stk, T, wr, a_t_min, INFINITY, cnt);
+        if (hold) trav_leaf<STATS>(S, stk, T, a_t_min, INFINITY, cnt);
       }
       RT_STAMP(7);  // leaf code
       // back to the shading phase when enough of the live lanes have a finished ray (RT_READY_LANES in 64)
@@ -2677,7 +2689,7 @@ struct Wide4Builder {
       const int sub_root = T->build_under(s->objects[~leaf.left].first);
       const int r = ref_of(sub_root, &sub);
       sub_root_ref[(size_t)~leaf.left] = r;
-      *need = 1 + sub;  // the marker that switches the lane back to the outer frame
+      *need = 4 + sub;  // the world ray (three entries) and the marker that switches the lane back to it
     }
     return ref_of_leaf(n.ref_node);
   }
