@@ -2509,7 +2509,6 @@ int build_bnodes(const rt_scene* s, int idx, std::vector<BNode>* out, std::vecto
     if (rc != RT_OK) return rc;
     return build_bnodes(s, n.right, out, prim_rank, rank);
   }
-  if (n.right > 255) return rt::set_error(RT_ERR_UNSUPPORTED, "a leaf list longer than 255 primitives");
   const int ref = ~n.left;
   if (n.right > 0) {
     for (int k = ref; k < ref + n.right; ++k) (*prim_rank)[(size_t)k] = *rank;

@@ -234,3 +234,37 @@ def test_medium_in_a_box_of_the_ten_times_room(gpu, orc):
     _, st64 = orc.render(flat, cam.c, p, mode=orc.ORC_F64, want_sumsq=False, want_stats=True)
     assert abs(st32.hits - st64.hits) < 0.003 * st64.hits, (st32.hits, st64.hits)
     _compare(gpu, orc, flat, cam, 48, 48, 64, same_frac=0.8)
+
+
+def test_long_lists_as_leaves_of_a_large_tree(gpu, orc):
+    """Leaves of 300 primitives, one a plain HitableList and one under
+    Translate(RotateY(..)), among 150 spheres: the per-lane stack traversal walks
+    such a list with a per-lane loop, whatever its length."""
+    with Scene(24) as sc:
+        cam, world = _sphere_field(150, 7, glass_and_metal=False)
+        rng = np.random.RandomState(3)
+        white = S.Lambertian.new_from_color(S.vec3(0.73, 0.73, 0.73))
+        red = S.Lambertian.new_from_color(S.vec3(0.65, 0.05, 0.05))
+
+        def slats(mat, n):
+            out = []
+            for k in range(n):
+                x0, z0 = float(rng.uniform(-2.0, 1.5)), float(rng.uniform(-2.0, 1.5))
+                out.append(S.XZRect.new(x0, x0 + 0.5, z0, z0 + 0.5, float(1.0 + 0.01 * k), mat))
+            return S.HitableList.new(out)
+
+        items = list(world.list)
+        items.append(slats(white, 300))
+        items.append(S.Translate.new(S.RotateY.new(slats(red, 300), 30.0), S.vec3(1.0, 0.5, -1.0)))
+        sc.light_xz_rect(-3.0, 3.0, -3.0, 3.0, 6.0)
+        flat = sc.flatten(S.HitableList.new(items))
+        assert flat.n_prims > 700
+        _compare(gpu, orc, flat, cam, 60, 40, 64, same_frac=0.85)
+        # and the nearest hits of rays aimed down at the slats, bit for bit
+        n = 6000
+        o = np.stack([rng.uniform(-2.5, 2.5, n), np.full(n, 5.5), rng.uniform(-2.5, 2.5, n)], axis=1).astype(np.float32)
+        d = np.stack([rng.uniform(-0.3, 0.3, n), np.full(n, -1.0), rng.uniform(-0.3, 0.3, n)], axis=1).astype(np.float32)
+        prim, t = gpu.trace_closest(o, d)
+        op, ot = orc.trace_closest(flat, o, d, mode=orc.ORC_F32_FUSED)
+        assert np.array_equal(prim, op) and np.array_equal(t, ot.astype(np.float32))
+        assert (prim >= 150).mean() > 0.3  # a good share of them end on a slat
