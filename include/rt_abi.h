@@ -351,6 +351,19 @@ int rt_trace_closest(rt_ctx* ctx, const float* o, const float* d, size_t n, floa
                      float t_max, int32_t* prim_id, float* t, float* normal_or_null,
                      float* p_or_null);
 
+/* The same query in the reference's own arithmetic, as a check on the fp32 path
+ * ("parity mode"): f64 throughout, a division where the source divides
+ * (src/bvh.rs:49, src/hitable.rs:59-61,165), no fused multiply-adds, and the
+ * source's traversal: every node of the tree as passed in gets its Aabb::hit, both
+ * children are visited with the same t_max and the right one wins an exact tie
+ * (src/bvh.rs:197-228).  None of the fp32 path's own steps applies.  Scene data are
+ * the uploaded fp32 arrays widened to f64 (what a Rust caller that flattens its f64
+ * scene into rt_scene has handed over).  Media are skipped.  One ray per lane, no
+ * pruning: it is a checker, orders of magnitude slower than rt_trace_closest. */
+int rt_trace_closest_f64(rt_ctx* ctx, const double* o, const double* d, size_t n, double t_min,
+                         double t_max, int32_t* prim_id, double* t, double* normal_or_null,
+                         double* p_or_null);
+
 /* main.rs:136-155: divide the sums by spp_total, sqrt, clamp high to 1,
  * (255.99*c) truncated to u8.  sum_rgb and rgb8 are host buffers. */
 int rt_tonemap(rt_ctx* ctx, const float* sum_rgb, int32_t nx, int32_t ny, int32_t spp_total,

@@ -141,6 +141,7 @@ def lib():
     sig("rt_multi_upload_scene", C.c_int, vp, C.POINTER(rt_scene))
     sig("rt_multi_render", C.c_int, vp, C.POINTER(rt_camera), C.POINTER(rt_render_params), C.c_int, vp, vp, vp)
     sig("rt_trace_closest", C.c_int, vp, vp, vp, C.c_size_t, C.c_float, C.c_float, vp, vp, vp, vp)
+    sig("rt_trace_closest_f64", C.c_int, vp, vp, vp, C.c_size_t, C.c_double, C.c_double, vp, vp, vp, vp)
     sig("rt_tonemap", C.c_int, vp, vp, C.c_int32, C.c_int32, C.c_int32, vp)
     sig("rt_selftest_reciprocal", C.c_int, vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32))
     sig("rt_build_lbvh", C.c_int, vp, C.POINTER(rt_scene), vp)

@@ -125,6 +125,8 @@ struct DevScene {
   const float4* box6_recs; // 5 float4 per record: the 18 floats of box6_test, padded
   const int* prim_rank;  // per primitive: depth-first rank of its leaf
   const rt_object* objects;
+  const rt_node* ref_nodes;  // the node array as it was passed in (trace64_kernel walks it the reference's way)
+  int n_ref_nodes;
   int stack_mode;
   int stack_depth;  // entries per lane of the traversal stack that the deepest walk can need
   int stack_lds;    // of which this many live in LDS
@@ -163,6 +165,7 @@ static_assert(sizeof(BNode4) == 128, "one cache line");
 #define BN2_LEAF 0x40000000
 #define BN2_PRIM 0x20000000  // with BN2_LEAF: a single-primitive leaf, the low bits are the primitive's index
 #define BN4_EMPTY (-2)
+#define RT_MAX_TREE_DEPTH 64  // rt_upload_scene refuses node trees deeper than this
 #define STACK_DEPTH 64  // deepest tree the stack traversal takes; the launch sizes the LDS stack to the scene's own depth
 #define STACK_RESTORE 0xffffffffu
 
@@ -1013,6 +1016,186 @@ __global__ void __launch_bounds__(256) trace_kernel(DevScene S, const float* __r
         if (p_out) { p_out[3 * idx] = s.p.x; p_out[3 * idx + 1] = s.p.y; p_out[3 * idx + 2] = s.p.z; }
       }
     }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// trace64_kernel: the nearest hit in the REFERENCE'S OWN ARITHMETIC (parity mode)
+// ---------------------------------------------------------------------------
+// f64 throughout, a division where the source divides, no fused multiply-adds, and the source's traversal: every node
+// of the tree as it was passed in gets its Aabb::hit (bvh.rs:198), both children are visited with the same t_max and the
+// right one wins an exact tie (bvh.rs:204-217).  None of the render path's fp32 steps (outward-widened slabs, the
+// perpendicular-offset discriminant, the re-projected sphere point) applies here.  It is a check, not a fast path: one
+// ray per lane, a private stack, no pruning.
+struct D3 {
+  double x, y, z;
+};
+__device__ __forceinline__ double d3_get(const D3& v, int a) { return a == 0 ? v.x : (a == 1 ? v.y : v.z); }
+__device__ __forceinline__ double d3_dot(const D3& a, const D3& b) { return a.x * b.x + a.y * b.y + a.z * b.z; }  // vec3.rs:176-178
+struct Hit64 {
+  double t;
+  int prim;
+  D3 p, n;
+};
+
+// Aabb::hit, bvh.rs:46-61
+__device__ __forceinline__ bool aabb_hit64(const rt_node& n, const D3& o, const D3& d, double t_min, double t_max) {
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const double inv_d = 1.0 / d3_get(d, a);
+    double t0 = ((double)n.bmin[a] - d3_get(o, a)) * inv_d;
+    double t1 = ((double)n.bmax[a] - d3_get(o, a)) * inv_d;
+    if (inv_d < 0.0) { const double tmp = t0; t0 = t1; t1 = tmp; }
+    t_min = t0 > t_min ? t0 : t_min;
+    t_max = t1 < t_max ? t1 : t_max;
+    if (t_max <= t_min) return false;
+  }
+  return true;
+}
+
+// XYRect/XZRect/YZRect::hit (hitable.rs:163-183 and twins) and Sphere::hit (hitable.rs:49-84), FlipNormals applied
+__device__ __forceinline__ bool prim_hit64(const rt_prim& q, int idx, const D3& o, const D3& d, double t0, double t1, Hit64& rec) {
+  const int type = q.type & RT_PRIM_TYPE_MASK;
+  if (type == RT_PRIM_SPHERE) {
+    const D3 c = {(double)q.f[0], (double)q.f[1], (double)q.f[2]};
+    const double radius = (double)q.f[3];
+    const D3 oc = {o.x - c.x, o.y - c.y, o.z - c.z};
+    const double a = d3_dot(d, d), b = d3_dot(oc, d), cc = d3_dot(oc, oc) - radius * radius;
+    const double disc = b * b - a * cc;
+    if (!(disc > 0.0)) return false;
+    const double sq = sqrt(disc);
+    for (int root = 0; root < 2; ++root) {
+      const double temp = root == 0 ? (-b - sq) / a : (-b + sq) / a;
+      if (temp < t1 && temp > t0) {
+        rec.t = temp;
+        rec.p = D3{o.x + d.x * temp, o.y + d.y * temp, o.z + d.z * temp};
+        rec.n = D3{(rec.p.x - c.x) / radius, (rec.p.y - c.y) / radius, (rec.p.z - c.z) / radius};
+        rec.prim = idx;
+        return true;
+      }
+    }
+    return false;
+  }
+  int c, ca, cb;
+  if (type == RT_PRIM_XY_RECT) { c = 2; ca = 0; cb = 1; }
+  else if (type == RT_PRIM_XZ_RECT) { c = 1; ca = 0; cb = 2; }
+  else { c = 0; ca = 1; cb = 2; }
+  const double a0 = q.f[0], a1 = q.f[1], b0 = q.f[2], b1 = q.f[3], k = q.f[4];
+  const double t = (k - d3_get(o, c)) / d3_get(d, c);
+  if (t < t0 || t > t1) return false;
+  const double a = d3_get(o, ca) + t * d3_get(d, ca);
+  const double b = d3_get(o, cb) + t * d3_get(d, cb);
+  if (a < a0 || a > a1 || b < b0 || b > b1) return false;
+  rec.t = t;
+  rec.prim = idx;
+  rec.p = D3{o.x + d.x * t, o.y + d.y * t, o.z + d.z * t};
+  const double s = (q.type & RT_PRIM_FLIP) ? -1.0 : 1.0;
+  // (the flipped zero components are -0.0 in the reference too: `-normal` negates every component, hitable.rs:341-353)
+  rec.n = D3{c == 0 ? s : s * 0.0, c == 1 ? s : s * 0.0, c == 2 ? s : s * 0.0};
+  return true;
+}
+
+// HitableList::hit, hitable.rs:105-117
+__device__ __forceinline__ bool list_hit64(const DevScene& S, int first, int count, const D3& o, const D3& d, double t_min, double t_max, Hit64& out) {
+  bool any = false;
+  double closest = t_max;
+  for (int i = first; i < first + count; ++i) {
+    Hit64 rec;
+    if (prim_hit64(S.prims[i], i, o, d, t_min, closest, rec)) {
+      closest = rec.t;
+      out = rec;
+      any = true;
+    }
+  }
+  return any;
+}
+
+// BvhNode::hit over the tree under `root` (bvh.rs:197-228), iteratively: the leaves are met left to right, every one is
+// tested against the same (t_min, t_max), and a leaf's hit replaces the one held unless that one is strictly nearer,
+// which is the source's `if left.t < right.t { left } else { right }` folded over the leaves.  OBJECTS: the world tree
+// (its leaves may be objects); false inside an object's own sub-tree (primitive leaves only).
+template <bool OBJECTS>
+__device__ bool tree_hit64(const DevScene& S, int root, const D3& o, const D3& d, double t_min, double t_max, Hit64& best);
+
+__device__ __forceinline__ bool object_hit64(const DevScene& S, const rt_object& ob, const D3& o, const D3& d, double t_min, double t_max, Hit64& rec) {
+  // Translate::hit around RotateY::hit, hitable.rs:438-446, 508-532
+  D3 lo = o, ld = d;
+  const double cos_t = (double)ob.cos_theta, sin_t = (double)ob.sin_theta;
+  const D3 off = {(double)ob.offset[0], (double)ob.offset[1], (double)ob.offset[2]};
+  if (ob.xform & RT_XFORM_TRANSLATE) lo = D3{lo.x - off.x, lo.y - off.y, lo.z - off.z};
+  if (ob.xform & RT_XFORM_ROTATE_Y) {
+    const D3 po = lo, pd = ld;
+    lo.x = cos_t * po.x - sin_t * po.z;
+    lo.z = sin_t * po.x + cos_t * po.z;
+    ld.x = cos_t * pd.x - sin_t * pd.z;
+    ld.z = sin_t * pd.x + cos_t * pd.z;
+  }
+  bool hit;
+  if (ob.kind == RT_OBJ_BVH) hit = tree_hit64<false>(S, ob.first, lo, ld, t_min, t_max, rec);
+  else hit = list_hit64(S, ob.first, ob.count, lo, ld, t_min, t_max, rec);
+  if (!hit) return false;
+  if (ob.xform & RT_XFORM_ROTATE_Y) {
+    const D3 p = rec.p, n = rec.n;
+    rec.p.x = cos_t * p.x + sin_t * p.z;
+    rec.p.z = -sin_t * p.x + cos_t * p.z;
+    rec.n.x = cos_t * n.x + sin_t * n.z;
+    rec.n.z = -sin_t * n.x + cos_t * n.z;
+  }
+  if (ob.xform & RT_XFORM_TRANSLATE) rec.p = D3{rec.p.x + off.x, rec.p.y + off.y, rec.p.z + off.z};
+  return true;
+}
+
+template <bool OBJECTS>
+__device__ bool tree_hit64(const DevScene& S, int root, const D3& o, const D3& d, double t_min, double t_max, Hit64& best) {
+  int stack[RT_MAX_TREE_DEPTH + 2];
+  int sp = 0;
+  stack[sp++] = root;
+  bool any = false;
+  while (sp > 0) {
+    const int idx = stack[--sp];
+    const rt_node n = S.ref_nodes[idx];
+    if (!aabb_hit64(n, o, d, t_min, t_max)) continue;
+    if (n.left >= 0) {
+      stack[sp++] = n.right;  // (popped after the left one: leaves are met left to right)
+      stack[sp++] = n.left;
+      continue;
+    }
+    Hit64 rec;
+    bool hit;
+    const int ref = ~n.left;
+    if (n.right > 0) {
+      hit = list_hit64(S, ref, n.right, o, d, t_min, t_max, rec);
+    } else {
+      if (!OBJECTS) continue;
+      const rt_object ob = S.objects[ref];
+      if (ob.kind == RT_OBJ_MEDIUM) continue;  // a deterministic query skips media, as rt_trace_closest does
+      hit = object_hit64(S, ob, o, d, t_min, t_max, rec);
+    }
+    if (hit && (!any || !(best.t < rec.t))) {
+      best = rec;
+      any = true;
+    }
+  }
+  return any;
+}
+
+__global__ void __launch_bounds__(64) trace64_kernel(DevScene S, const double* __restrict__ o, const double* __restrict__ d, size_t n, double t_min,
+                                                     double t_max, int* __restrict__ prim_id, double* __restrict__ t_out,
+                                                     double* __restrict__ normal, double* __restrict__ p_out) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const D3 ro = {o[3 * i], o[3 * i + 1], o[3 * i + 2]}, rd = {d[3 * i], d[3 * i + 1], d[3 * i + 2]};
+    Hit64 best;
+    best.t = 0.0;
+    best.prim = -1;
+    best.p = D3{0.0, 0.0, 0.0};
+    best.n = D3{0.0, 0.0, 0.0};
+    Hit64 rec;
+    if (S.n_ref_nodes > 0 && tree_hit64<true>(S, 0, ro, rd, t_min, t_max, rec)) best = rec;
+    prim_id[i] = best.prim;
+    t_out[i] = best.t;
+    if (normal) { normal[3 * i] = best.n.x; normal[3 * i + 1] = best.n.y; normal[3 * i + 2] = best.n.z; }
+    if (p_out) { p_out[3 * i] = best.p.x; p_out[3 * i + 1] = best.p.y; p_out[3 * i + 2] = best.p.z; }
   }
 }
 
@@ -2132,6 +2315,7 @@ struct rt_ctx {
   DevScene dev;
   void* d_scan;
   void* d_prims;
+  void* d_ref_nodes;
   void* d_dprims;
   void* d_leaf_box;
   void* d_bnodes;
@@ -2174,7 +2358,7 @@ int hip_fail(hipError_t e, const char* what) {
   } while (0)
 
 void free_scene(rt_ctx* ctx) {
-  void** ptrs[] = {&ctx->d_scan, &ctx->d_prims, &ctx->d_dprims, &ctx->d_leaf_box, &ctx->d_bnodes, &ctx->d_bnodes4, &ctx->d_sub_root_ref, &ctx->d_box6_index, &ctx->d_box6_recs, &ctx->d_prim_rank, &ctx->d_objects, &ctx->d_materials, &ctx->d_textures, &ctx->d_perlins, &ctx->d_lights};
+  void** ptrs[] = {&ctx->d_scan, &ctx->d_prims, &ctx->d_ref_nodes, &ctx->d_dprims, &ctx->d_leaf_box, &ctx->d_bnodes, &ctx->d_bnodes4, &ctx->d_sub_root_ref, &ctx->d_box6_index, &ctx->d_box6_recs, &ctx->d_prim_rank, &ctx->d_objects, &ctx->d_materials, &ctx->d_textures, &ctx->d_perlins, &ctx->d_lights};
   for (size_t i = 0; i < sizeof(ptrs) / sizeof(ptrs[0]); ++i) {
     if (*ptrs[i]) (void)hipFree(*ptrs[i]);
     *ptrs[i] = nullptr;
@@ -3148,6 +3332,7 @@ int rt_upload_scene(rt_ctx* ctx, const rt_scene* s) {
   free_scene(ctx);
   if ((rc = upload(&ctx->d_scan, scan.data(), scan.size())) != RT_OK) return rc;
   if ((rc = upload(&ctx->d_prims, s->prims, (size_t)s->n_prims)) != RT_OK) return rc;
+  if ((rc = upload(&ctx->d_ref_nodes, s->nodes, (size_t)s->n_nodes)) != RT_OK) return rc;
   // One DevPrim per primitive: geometry + the frame it lives in + its material.
   std::vector<DevPrim> dprims((size_t)s->n_prims + B.media.size());
   int mat_mask = 0, textured = 0;
@@ -3203,6 +3388,8 @@ int rt_upload_scene(rt_ctx* ctx, const rt_scene* s) {
   std::memset(&d, 0, sizeof(d));
   d.scan = (const ScanNode*)ctx->d_scan;
   d.prims = (const rt_prim*)ctx->d_prims;
+  d.ref_nodes = (const rt_node*)ctx->d_ref_nodes;
+  d.n_ref_nodes = s->n_nodes;
   d.dprims = (const DevPrim*)ctx->d_dprims;
   d.leaf_box = (const float4*)ctx->d_leaf_box;
   // flat: leaves only, and few enough primitives for the render kernel's LDS tables
@@ -3354,6 +3541,38 @@ int rt_trace_closest(rt_ctx* ctx, const float* o, const float* d, size_t n, floa
   if (e == hipSuccess && normal) e = hipMemcpy(normal, d_n, n * 3 * sizeof(float), hipMemcpyDeviceToHost);
   if (e == hipSuccess && p) e = hipMemcpy(p, d_p, n * 3 * sizeof(float), hipMemcpyDeviceToHost);
   if (e != hipSuccess) return hip_fail(e, "rt_trace_closest");
+  return RT_OK;
+}
+
+int rt_trace_closest_f64(rt_ctx* ctx, const double* o, const double* d, size_t n, double t_min, double t_max, int32_t* prim_id, double* t,
+                         double* normal, double* p) {
+  if (!ctx || !o || !d || !prim_id || !t) return rt::set_error(RT_ERR_INVALID, "rt_trace_closest_f64: null argument");
+  if (!ctx->has_scene) return rt::set_error(RT_ERR_NO_SCENE, "rt_trace_closest_f64: no scene uploaded");
+  if (n == 0) return RT_OK;
+  HIP_TRY(hipSetDevice(ctx->device));
+  double *d_o = nullptr, *d_d = nullptr, *d_t = nullptr, *d_n = nullptr, *d_p = nullptr;
+  int* d_id = nullptr;
+  int rc;
+  if ((rc = stage(ctx, 0, n * 3 * sizeof(double), (void**)&d_o)) != RT_OK) return rc;
+  if ((rc = stage(ctx, 1, n * 3 * sizeof(double), (void**)&d_d)) != RT_OK) return rc;
+  if ((rc = stage(ctx, 2, n * sizeof(double), (void**)&d_t)) != RT_OK) return rc;
+  if ((rc = stage(ctx, 3, n * sizeof(int), (void**)&d_id)) != RT_OK) return rc;
+  if (normal && (rc = stage(ctx, 4, n * 3 * sizeof(double), (void**)&d_n)) != RT_OK) return rc;
+  if (p && (rc = stage(ctx, 5, n * 3 * sizeof(double), (void**)&d_p)) != RT_OK) return rc;
+  hipError_t e = hipMemcpy(d_o, o, n * 3 * sizeof(double), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(d_d, d, n * 3 * sizeof(double), hipMemcpyHostToDevice);
+  if (e == hipSuccess) {
+    size_t blocks = (n + 63) / 64;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(trace64_kernel, dim3((unsigned)blocks), dim3(64), 0, 0, ctx->dev, d_o, d_d, n, t_min, t_max, d_id, d_t, d_n, d_p);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipDeviceSynchronize();
+  if (e == hipSuccess) e = hipMemcpy(prim_id, d_id, n * sizeof(int), hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = hipMemcpy(t, d_t, n * sizeof(double), hipMemcpyDeviceToHost);
+  if (e == hipSuccess && normal) e = hipMemcpy(normal, d_n, n * 3 * sizeof(double), hipMemcpyDeviceToHost);
+  if (e == hipSuccess && p) e = hipMemcpy(p, d_p, n * 3 * sizeof(double), hipMemcpyDeviceToHost);
+  if (e != hipSuccess) return hip_fail(e, "rt_trace_closest_f64");
   return RT_OK;
 }
 

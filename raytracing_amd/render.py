@@ -90,6 +90,28 @@ class Renderer(object):
             out.append(p)
         return tuple(out)
 
+    def trace_closest_f64(self, o, d, t_min=0.001, t_max=float("inf"), want_normal=False, want_p=False):
+        """The same query in the reference's own arithmetic (f64, the source's
+        divisions and traversal order): rt_trace_closest_f64, the parity mode."""
+        o = np.ascontiguousarray(o, dtype=np.float64)
+        d = np.ascontiguousarray(d, dtype=np.float64)
+        if o.ndim != 2 or o.shape[1] != 3 or o.shape != d.shape:
+            raise ValueError("o and d must both have shape (n, 3)")
+        n = o.shape[0]
+        prim = np.zeros(n, dtype=np.int32)
+        t = np.zeros(n, dtype=np.float64)
+        normal = np.zeros((n, 3), dtype=np.float64) if want_normal else None
+        p = np.zeros((n, 3), dtype=np.float64) if want_p else None
+        check(_lib.lib().rt_trace_closest_f64(self._ctx, o.ctypes.data, d.ctypes.data, n, t_min, t_max, prim.ctypes.data,
+                                              t.ctypes.data, normal.ctypes.data if want_normal else None,
+                                              p.ctypes.data if want_p else None))
+        out = [prim, t]
+        if want_normal:
+            out.append(normal)
+        if want_p:
+            out.append(p)
+        return tuple(out)
+
     def tonemap(self, sum_rgb, spp_total):
         """main.rs:136-155 on the device: u8 RGB, shape (ny, nx, 3)."""
         a = np.ascontiguousarray(sum_rgb, dtype=np.float32)

@@ -75,6 +75,19 @@ def test_million_sphere_tree_nearest_hits(gpu, orc, stress_scene):
     assert len(np.unique(prim)) > 5000  # spread over the tree, not a corner of it
 
 
+def test_million_sphere_tree_in_the_reference_arithmetic(gpu, orc, stress_scene):
+    """The same tree walked by rt_trace_closest_f64 (f64, the source's divisions and
+    traversal order) against the f64 oracle: primitive, t, point and normal bit for bit."""
+    cam, flat = stress_scene
+    gpu.upload_scene(flat)
+    o, d = _stress_rays(cam, 24000, 13)
+    prim, t, nrm, p = gpu.trace_closest_f64(o.astype(np.float64), d.astype(np.float64), want_normal=True, want_p=True)
+    op, ot, on, opp = orc.trace_closest(flat, o, d, mode=orc.ORC_F64, want_normal=True, want_p=True)
+    assert np.array_equal(prim, op) and np.array_equal(t, ot)
+    assert np.array_equal(nrm, on) and np.array_equal(p, opp)
+    assert (prim >= 0).mean() > 0.5 and len(np.unique(prim)) > 5000
+
+
 def test_million_sphere_device_built_tree_nearest_hits(gpu, orc, stress_scene):
     """The same rays through the tree rt_build_lbvh makes on the device from the
     same 2^20+1 leaves: the oracle walks that node array too, so parity is again

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """A longer run of the randomised nearest-hit parity of tests/test_gpu_fuzz.py: N random scenes (1 to 600 items of every
 hitable and nesting the flattener takes), 20,000 rays each, device against the fp32 oracle bit for bit (primitive, t,
-normal, point), through the tree as given and through the device-built one.  tools/fuzz_soak.py [N [first_seed]]
+normal, point), through the tree as given and through the device-built one, and the f64 parity mode against the f64 oracle.  tools/fuzz_soak.py [N [first_seed]]
 (on the GPU box; prints one line per scene that differs and a summary)."""
 import os
 import sys
@@ -44,6 +44,14 @@ for k in range(n_scenes):
             oprim, ot, onrm, op = orc.trace_closest(scene, o, d, mode=orc.ORC_F32_FUSED, want_normal=True, want_p=True)
             ok = (np.array_equal(prim, oprim) and np.array_equal(t, ot.astype(np.float32)) and
                   np.array_equal(nrm, onrm.astype(np.float32)) and np.array_equal(p, op.astype(np.float32)))
+            if name == "given":
+                # the parity mode: the device in the reference's own arithmetic against the f64 oracle
+                p64, t64, n64, x64 = gpu.trace_closest_f64(o.astype(np.float64), d.astype(np.float64), want_normal=True, want_p=True)
+                q64, u64, m64, y64 = orc.trace_closest(scene, o, d, mode=orc.ORC_F64, want_normal=True, want_p=True)
+                if not (np.array_equal(p64, q64) and np.array_equal(t64, u64) and np.array_equal(n64, m64) and np.array_equal(x64, y64)):
+                    ok = False
+                    print("  (f64 parity mode differs: %d primitive ids, %d t values)" % (int((p64 != q64).sum()), int((t64 != u64).sum())), flush=True)
+                rays += m
             rays += m
             if not ok:
                 bad_scenes += 1
