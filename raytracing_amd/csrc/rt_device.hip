@@ -164,6 +164,7 @@ struct BNode4 {
 static_assert(sizeof(BNode4) == 128, "one cache line");
 #define BN2_LEAF 0x40000000
 #define BN2_PRIM 0x20000000  // with BN2_LEAF: a single-primitive leaf, the low bits are the primitive's index
+#define BN2_BOX6 0x10000000  // with BN2_LEAF: a list of six rects in Cuboid::new's order, the low bits are its record's index
 #define BN4_EMPTY (-2)
 #define RT_MAX_TREE_DEPTH 64  // rt_upload_scene refuses node trees deeper than this
 #define STACK_DEPTH 64  // deepest tree the stack traversal takes; the launch sizes the LDS stack to the scene's own depth
@@ -706,6 +707,7 @@ template <bool STATS>
 __device__ __forceinline__ void box6_lane(const DevScene& S, int rec, int first, const RayF& r, float t_min, float t_max, Hit& best, Counters& cnt) {
   const float4* src = (const float4*)((const char*)S.box6_recs + (unsigned)rec * 80u);
   const float4 v0 = src[0], v1 = src[1], v2 = src[2], v3 = src[3], v4 = src[4];
+  if (first < 0) first = __float_as_int(v4.z);  // (a lane that came by the record alone: the record names its list)
   const float g[18] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w, v3.x, v3.y, v3.z, v3.w, v4.x, v4.y};
   float loc_t = t_max;
   int loc_k = -1;
@@ -845,7 +847,12 @@ template <bool STATS, class STK>
 __device__ __forceinline__ void trav_leaf(const DevScene& S, STK& stk, Trav& T, float t_min, float t_max, Counters& cnt) {
   const int node = T.cur & BN_INDEX_MASK;
   const bool single = (T.cur & BN2_PRIM) != 0;
+  const bool by_record = (T.cur & BN2_BOX6) != 0;
   T.cur = TRAV_POP;
+  if (by_record) {
+    box6_lane<STATS>(S, node, -1, T.r, t_min, t_max, T.best, cnt);
+    return;
+  }
   int ref = node, count = 1;
   if (!single) {
     ref = ~S.bnodes[node].left;
@@ -2210,7 +2217,7 @@ __global__ void __launch_bounds__(64, GENERAL < 2 ? RT_STACK_WAVES : 5) render_s
       const unsigned long long m_trav = __ballot(trav), m_hold = __ballot(hold);
       // the leaf code runs once for all lanes that hold a leaf, when enough of the traversing lanes do
       if (m_hold != 0ull && __popcll(m_hold) * 64 >= a_hold * __popcll(m_trav)) {
-        RT_COUNT(12, 1); RT_COUNT(13, __popcll(m_hold));
+        RT_COUNT(12, 1); RT_COUNT(13, __popcll(m_hold)); RT_COUNT(14, __popcll(__ballot(hold & ((T.cur & BN2_PRIM) != 0))));
         if (hold) trav_leaf<STATS>(S, stk, T, a_t_min, INFINITY, cnt);
       }
       RT_STAMP(7);  // leaf code
@@ -2857,9 +2864,13 @@ struct Wide4Builder {
   TreeBuilder* T;
   std::vector<BNode4> out;
   std::vector<int> sub_root_ref;  // per object
+  const std::vector<int>* box6_index = nullptr;  // per primitive: the six-rect record that starts there, or -1
   int ref_of_leaf(int ref_node) const {
     const rt_node& c = s->nodes[ref_node];
-    return c.right == 1 ? (BN2_LEAF | BN2_PRIM | ~c.left) : (BN2_LEAF | ref_node);
+    if (c.right == 1) return BN2_LEAF | BN2_PRIM | ~c.left;
+    // a Cuboid's list goes by its record (one fetch at the leaf instead of node, index and record one after the other)
+    if (c.right == 6 && box6_index && (*box6_index)[(size_t)~c.left] >= 0) return BN2_LEAF | BN2_BOX6 | (*box6_index)[(size_t)~c.left];
+    return BN2_LEAF | ref_node;
   }
   // the reference of built node `idx` (interior: builds its entry) and the stack it needs
   int ref_of(int idx, int* need) {
@@ -3279,15 +3290,6 @@ int rt_upload_scene(rt_ctx* ctx, const rt_scene* s) {
   std::vector<int> box6_index((size_t)s->n_prims, -1);
   std::vector<float> box6_recs;
   if (want_stack) {
-    root_ref = W.ref_of(TB.build_under(0), &stack_need);
-    if (stack_need + 2 > RT_STACK_MAX) {
-      // the heuristic's tree is too deep for a lane's stack: the balanced one over the same leaves
-      TB.nodes.clear();
-      TB.halve_only = true;
-      W.out.clear();
-      root_ref = W.ref_of(TB.build_under(0), &stack_need);
-    }
-    if (W.out.size() > (size_t)BN_INDEX_MASK) return rt::set_error(RT_ERR_UNSUPPORTED, "too many nodes");
     auto note_box6 = [&](int first, int count) {
       if (!box6_flag(s, first, count)) return;
       box6_index[(size_t)first] = (int)(box6_recs.size() / 20);
@@ -3300,12 +3302,24 @@ int rt_upload_scene(rt_ctx* ctx, const rt_scene* s) {
         g[6 * pair + 4] = q0.f[4];
         g[6 * pair + 5] = q1.f[4];
       }
+      std::memcpy(&g[18], &first, sizeof(int));  // the list's first primitive, for a lane that comes by the record alone
       box6_recs.insert(box6_recs.end(), g, g + 20);
     };
     for (int i = 0; i < s->n_nodes; ++i)
       if (s->nodes[i].left < 0 && s->nodes[i].right > 1) note_box6(~s->nodes[i].left, s->nodes[i].right);
     for (int i = 0; i < s->n_objects; ++i)
       if (s->objects[i].kind == RT_OBJ_LIST) note_box6(s->objects[i].first, s->objects[i].count);
+    if (box6_recs.size() / 20 > (size_t)BN_INDEX_MASK) return rt::set_error(RT_ERR_UNSUPPORTED, "too many cuboids");
+    W.box6_index = &box6_index;
+    root_ref = W.ref_of(TB.build_under(0), &stack_need);
+    if (stack_need + 2 > RT_STACK_MAX) {
+      // the heuristic's tree is too deep for a lane's stack: the balanced one over the same leaves
+      TB.nodes.clear();
+      TB.halve_only = true;
+      W.out.clear();
+      root_ref = W.ref_of(TB.build_under(0), &stack_need);
+    }
+    if (W.out.size() > (size_t)BN_INDEX_MASK) return rt::set_error(RT_ERR_UNSUPPORTED, "too many nodes");
   }
   // a tree whose walk could need more stack than a lane has (LDS part + private part) takes the scan
   const bool stack_mode = want_stack && stack_need + 2 <= RT_STACK_MAX;
@@ -3479,6 +3493,7 @@ int rt_render(rt_ctx* ctx, const rt_camera* cam, const rt_render_params* params,
       for (int k = 0; k < 8; ++k) std::fprintf(stderr, "  phase %-16s %6.2f %%\n", names[k], 100.0 * (double)v[16 + k] / total);
       std::fprintf(stderr, "  shading phases %llu, lanes per phase %.1f; step trips %llu, lanes per trip %.1f; leaf rounds %llu, lanes per round %.1f\n",
                    v[24], (double)v[25] / (double)(v[24] ? v[24] : 1), v[26], (double)v[27] / (double)(v[26] ? v[26] : 1), v[28], (double)v[29] / (double)(v[28] ? v[28] : 1));
+      std::fprintf(stderr, "  of the lanes in leaf rounds, %.1f %% held a leaf of one primitive (the rest a list or an object)\n", 100.0 * (double)v[30] / (double)(v[29] ? v[29] : 1));
     }
 #endif
     if (e == hipSuccess) {
