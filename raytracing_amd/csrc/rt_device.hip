@@ -2735,15 +2735,18 @@ struct TreeBuilder {
   // the reference leaves under reference node idx, in the reference's depth-first order (objects are leaves here)
   // A BvhNode used as an item without Translate or RotateY lives in its parent's frame: its leaves join the parent's
   // tree (the same argument: a leaf of it is reached exactly when the ray passes that leaf's own box).
-  void collect(int idx, std::vector<int>* out) const {
+  // A ConstantMedium is no leaf of this tree: the render kernel walks the media after the tree (they draw random
+  // numbers) and a deterministic query skips them, so a lane that reached one would only fetch its records and leave;
+  // the global mist of the final scene, whose box is the whole scene, cost every ray one such visit.
+  void collect(int idx, std::vector<int>* out, bool media = false) const {
     const rt_node& n = s->nodes[idx];
     if (n.left < 0) {
-      if (n.right == 0 && s->objects[~n.left].kind == RT_OBJ_BVH && (s->objects[~n.left].xform & 3) == 0) collect(s->objects[~n.left].first, out);
-      else out->push_back(idx);
+      if (n.right == 0 && s->objects[~n.left].kind == RT_OBJ_BVH && (s->objects[~n.left].xform & 3) == 0) collect(s->objects[~n.left].first, out, media);
+      else if (media || !(n.right == 0 && s->objects[~n.left].kind == RT_OBJ_MEDIUM)) out->push_back(idx);
       return;
     }
-    collect(n.left, out);
-    collect(n.right, out);
+    collect(n.left, out, media);
+    collect(n.right, out, media);
   }
   int make_leaf(int ref) {
     const rt_node& n = s->nodes[ref];
@@ -2852,6 +2855,7 @@ struct TreeBuilder {
   int build_under(int idx) {
     std::vector<int> leaves;
     collect(idx, &leaves);
+    if (leaves.empty()) collect(idx, &leaves, true);  // (a world of media only: the tree keeps them so that it has a leaf)
     return build(leaves, 0, (int)leaves.size());
   }
 };
@@ -3182,9 +3186,11 @@ int rt::enqueue_render(rt_ctx* ctx, const rt_camera* cam, const rt_render_params
   return launch_render(ctx, cam, params, d_sum, d_sumsq, stats, (hipStream_t)stream);
 }
 
-int rt::reset_counters(rt_ctx* ctx) {
+// On the stream the counting launch will go to, so that the two are ordered: a hipMemset on the null stream can still be
+// pending when a kernel on a non-blocking stream has already added its counts.
+int rt::reset_counters(rt_ctx* ctx, void* hip_stream) {
   HIP_TRY(hipSetDevice(ctx->device));
-  HIP_TRY(hipMemset(ctx->d_stats, 0, 32 * sizeof(unsigned long long)));
+  HIP_TRY(hipMemsetAsync(ctx->d_stats, 0, 32 * sizeof(unsigned long long), (hipStream_t)hip_stream));
   return RT_OK;
 }
 

@@ -16,7 +16,7 @@ int context_device(const struct ::rt_ctx* ctx);
 int enqueue_render(struct ::rt_ctx* ctx, const struct rt_camera* cam, const struct rt_render_params* params, float* d_sum,
                    float* d_sumsq_or_null, bool stats, void* stream);
 // Zeroes / reads the event counters of the context's counting build (the device must be idle for the read).
-int reset_counters(struct ::rt_ctx* ctx);
+int reset_counters(struct ::rt_ctx* ctx, void* hip_stream);
 int read_counters(struct ::rt_ctx* ctx, struct rt_stats* out);
 }  // namespace rt
 

@@ -359,7 +359,7 @@ int rt_multi_render(rt_multi* m, const rt_camera* cam, const rt_render_params* p
       p.shard_index = r;
       p.shard_count = N;
     }
-    if (stats_per_rank && (rc = rt::reset_counters(m->ctx[(size_t)r])) != RT_OK) return rc;
+    if (stats_per_rank && (rc = rt::reset_counters(m->ctx[(size_t)r], (void*)m->stream[(size_t)r])) != RT_OK) return rc;
     HIP_TRY(hipSetDevice(m->device[(size_t)r]));
     HIP_TRY(hipEventRecord(m->t0[(size_t)r], m->stream[(size_t)r]));
     rc = rt::enqueue_render(m->ctx[(size_t)r], cam, &p, m->frame[(size_t)r], out_sumsq ? m->frame2[(size_t)r] : nullptr, stats_per_rank != nullptr,
