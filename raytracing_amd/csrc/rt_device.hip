@@ -1,9 +1,14 @@
 // rt_device.hip -- gfx950 kernels and the rt_* entry points of include/rt_abi.h.
 //
 // Kernels:
-//   render_kernel      : the whole sample loop of main.rs:96-116 with color()
-//                        (main.rs:165-209) unrolled into an iterative path loop.
-//   trace_kernel       : nearest hit for a batch of rays (the world.hit of main.rs:166).
+//   render_kernel       : the whole sample loop of main.rs:96-116 with color()
+//                         (main.rs:165-209) unrolled into an iterative path loop; scenes of a
+//                         handful of leaves and scenes on the skip-link scan.
+//   render_stack_kernel : the same loop for scenes on the per-lane stack traversal: a lane's
+//                         walk through the tree goes on across the shading code (see there).
+//   trace_kernel        : nearest hit for a batch of rays (the world.hit of main.rs:166).
+//   trace64_kernel      : the same in the reference's own arithmetic (f64, the source's
+//                         divisions and traversal order): the parity mode.
 //   reduce_slabs_kernel, tonemap_kernel, selftest_rcp_kernel : small helpers.
 //
 // Execution model of render_kernel.  One single-wave workgroup owns a work item:
@@ -20,7 +25,9 @@
 //                with a wave-uniform index, leaf data arriving through scalar loads
 //                into SGPRs; the leaves' box tests are deferred to the winner.
 //   TRAV_SCAN  - the same walk over a depth-first array with skip links.
-//   TRAV_STACK - larger trees: every lane follows its own ray with a stack in LDS.
+//   TRAV_STACK - larger trees: every lane follows its own ray through a four-wide tree that the
+//                upload builds over the given leaves, with a stack in LDS (and, for the rare
+//                deep walk, in global memory).
 // In the first two, leaves are met in the reference's left-to-right order, so
 // BvhNode::hit's "right wins ties" rule (bvh.rs:212-217) becomes "a later hit
 // replaces the best unless best < t"; the third keeps a depth-first rank per leaf.
