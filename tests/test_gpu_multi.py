@@ -116,3 +116,21 @@ def test_cpp_host_program_over_three_ranks(gpu, tmp_path):
     for other in (three, tiles):
         b = read_png(other).astype(np.int32)
         assert np.abs(a - b).max() <= 1 and (a != b).mean() < 1e-3
+
+
+def test_per_rank_event_counts_are_complete(gpu, cornell):
+    """Every rank's counters are zeroed on that rank's own stream, in order with its
+    counting launch: eight ranks on one device, five renders in a row, and the paths
+    the ranks report always add up to the whole image."""
+    nx, ny, spp = 160, 120, 64
+    p = make_params(nx, ny, spp, seed=3)
+    m = MultiRenderer([0] * 8)
+    try:
+        m.upload_scene(cornell.flat)
+        for _ in range(5):
+            for mode in ("samples", "tiles"):
+                _, stats = m.render(cornell.camera, p, mode=mode, want_stats=True)
+                assert sum(st.paths for st in stats) == nx * ny * spp, mode
+                assert all(st.rays >= st.paths for st in stats)
+    finally:
+        m.close()
