@@ -748,17 +748,28 @@ __device__ __forceinline__ void leaf_list_lane(const DevScene& S, int first, int
 #ifndef RT_STACK_LDS_RENDER
 #define RT_STACK_LDS_RENDER 10  // entries (of two dwords) the render kernel keeps in LDS
 #endif
+// (The two parts are pointers into their own address spaces, so that an access is a ds_ or a global_ instruction under
+// a branch: with plain pointers the compiler selects between the two addresses and issues one FLAT access, which for
+// the LDS part takes the global path's latency and waits on both memory counters.)
+typedef __attribute__((address_space(3))) unsigned lds_u32;
+typedef __attribute__((address_space(1))) unsigned glb_u32;
 template <bool OVF>
 struct LaneStackT {
-  unsigned* lds;  // this lane's column: entry `at` is the pair lds[at * 128] (reference), lds[at * 128 + 64] (distance key)
-  int n_lds;      // entries in LDS
-  unsigned* ovf;  // this lane's column of the wave's overflow region, same layout (OVF only)
+  lds_u32* lds;  // this lane's column: entry `at` is the pair lds[at * 128] (reference), lds[at * 128 + 64] (distance key)
+  int n_lds;     // entries in LDS
+  glb_u32* ovf;  // this lane's column of the wave's overflow region, same layout (OVF only)
   __device__ __forceinline__ void put(int at, unsigned ref, unsigned key) {
     if (!OVF || at < n_lds) { lds[at * 128] = ref; lds[at * 128 + 64] = key; }
     else { ovf[(at - n_lds) * 128] = ref; ovf[(at - n_lds) * 128 + 64] = key; }
   }
-  __device__ __forceinline__ unsigned get(int at) const { return (!OVF || at < n_lds) ? lds[at * 128] : ovf[(at - n_lds) * 128]; }
-  __device__ __forceinline__ unsigned get_key(int at) const { return (!OVF || at < n_lds) ? lds[at * 128 + 64] : ovf[(at - n_lds) * 128 + 64]; }
+  __device__ __forceinline__ unsigned get(int at) const {
+    if (!OVF || at < n_lds) return lds[at * 128];
+    return ovf[(at - n_lds) * 128];
+  }
+  __device__ __forceinline__ unsigned get_key(int at) const {
+    if (!OVF || at < n_lds) return lds[at * 128 + 64];
+    return ovf[(at - n_lds) * 128 + 64];
+  }
 };
 
 // The state of one lane's walk through the four-wide tree.
@@ -900,7 +911,7 @@ template <bool STATS>
 __device__ __forceinline__ void trace_stack(const DevScene& S, unsigned* __restrict__ stk_lds, const RayF& w, float t_min, float t_max, Hit& best,
                                             Counters& cnt) {
   LaneStackT<false> stk;
-  stk.lds = stk_lds;
+  stk.lds = (lds_u32*)stk_lds;
   stk.n_lds = S.stack_lds;
   stk.ovf = nullptr;
   Trav T;
@@ -1242,7 +1253,10 @@ __device__ __forceinline__ unsigned perlin_cell(float f) {
 }
 
 // Perlin::noise (perlin.rs:29-50) with perlin_interpolate (perlin.rs:102-124).
-__device__ __forceinline__ float perlin_noise(const rt_perlin* __restrict__ pn, F3 p) {
+__device__ __forceinline__ float perlin_noise(const rt_perlin* __restrict__ pn_generic, F3 p) {
+  // (the tables are in global memory; said so, the reads are global_ loads and not FLAT ones, which the out-of-line
+  // perlin_turb would otherwise get because it cannot see where its pointer comes from)
+  const __attribute__((address_space(1))) rt_perlin* pn = (const __attribute__((address_space(1))) rt_perlin*)pn_generic;
   const float fx = floorf(p.x), fy = floorf(p.y), fz = floorf(p.z);
   const float u = p.x - fx, v = p.y - fy, w = p.z - fz;
   const unsigned i = perlin_cell(fx), j = perlin_cell(fy), k = perlin_cell(fz);
@@ -1258,7 +1272,7 @@ __device__ __forceinline__ float perlin_noise(const rt_perlin* __restrict__ pn, 
 #pragma unroll
       for (int dk = 0; dk < 2; ++dk) {
         const int idx = pn->perm_x[(i + di) & 255u] ^ pn->perm_y[(j + dj) & 255u] ^ pn->perm_z[(k + dk) & 255u];
-        const float* c = pn->ranvec[idx & 255];
+        const __attribute__((address_space(1))) float* c = pn->ranvec[idx & 255];
         const float wi = di ? uu : 1.0f - uu, wj = dj ? vv : 1.0f - vv, wk = dk ? ww : 1.0f - ww;
         accum += wi * wj * wk * (c[0] * (u - (float)di) + c[1] * (v - (float)dj) + c[2] * (w - (float)dk));
       }
@@ -1909,9 +1923,9 @@ __global__ void __launch_bounds__(64, GENERAL < 2 ? RT_STACK_WAVES : 5) render_s
   __shared__ int slot_info[RT_SLOTS][4];  // tile x, tile y, chunk
   extern __shared__ float4 prim_lds[];  // the LDS part of the traversal stack: A.stack_lds entries of 64 lanes
   LaneStackT<true> stk;
-  stk.lds = (unsigned*)prim_lds + (threadIdx.x & 63);
+  stk.lds = (lds_u32*)((unsigned*)prim_lds + (threadIdx.x & 63));
   stk.n_lds = A.stack_lds;
-  stk.ovf = A.stack_ovf + (size_t)blockIdx.x * (size_t)(S.stack_depth - A.stack_lds) * 128 + (threadIdx.x & 63);
+  stk.ovf = (glb_u32*)(A.stack_ovf + (size_t)blockIdx.x * (size_t)(S.stack_depth - A.stack_lds) * 128 + (threadIdx.x & 63));
   const int lane = threadIdx.x & 63;
   __shared__ float cam_lds[20];
   if (lane == 0) {
