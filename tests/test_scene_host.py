@@ -313,7 +313,7 @@ def test_fp32_tree_walk_sees_thin_boxes_from_far_origins():
 
 
 def test_rust_declarations_in_the_integration_notes_follow_the_header():
-    """The `#[repr(C)]` structs a maintainer would paste from INTEGRATION.md list the
+    """The `#[repr(C)]` structs a maintainer would paste from the integration notes list the
     fields of include/rt_abi.h's structs in the same order with the same types, and
     every `pub fn` there is a symbol the header declares."""
     header = open(os.path.join(ROOT, "include", "rt_abi.h")).read() + open(os.path.join(ROOT, "include", "rt_scene_api.h")).read()
