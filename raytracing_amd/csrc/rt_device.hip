@@ -525,6 +525,74 @@ __device__ __forceinline__ void box6_test(const ScanNode* __restrict__ scan, int
   best.prim = take ? first + loc_k : best.prim;
 }
 
+// The two boundary searches of ConstantMedium::hit (hitable.rs:562-566) over a Cuboid's six rects in one pass: a
+// rect's t and whether its hit point lies inside the rect do not depend on the interval searched, so they are computed
+// once per rect, and each search then walks the six (t, inside) pairs the way HitableList::hit walks the rects (the
+// upper bound shrinks to every hit accepted, a later rect wins an equal t).  Same arithmetic, same comparisons and same
+// order as two box6_test calls; 96 instructions instead of 150.  `next_of` maps the first search's t to the second's
+// lower bound.
+template <int C, int A, int B>
+__device__ __forceinline__ void rect_parts(const float* f, float k, const RayF& r, float& t, bool& inside) {
+  const float oc = C == 0 ? r.o.x : (C == 1 ? r.o.y : r.o.z);
+  const float ic = C == 0 ? r.inv.x : (C == 1 ? r.inv.y : r.inv.z);
+  const float oa = A == 0 ? r.o.x : (A == 1 ? r.o.y : r.o.z);
+  const float da = A == 0 ? r.d.x : (A == 1 ? r.d.y : r.d.z);
+  const float ob = B == 0 ? r.o.x : (B == 1 ? r.o.y : r.o.z);
+  const float db = B == 0 ? r.d.x : (B == 1 ? r.d.y : r.d.z);
+  t = (k - oc) * ic;
+  const float a = fmaf(t, da, oa);
+  const float b = fmaf(t, db, ob);
+  const float ma = __builtin_amdgcn_fmed3f(a, f[0], f[1]), mb = __builtin_amdgcn_fmed3f(b, f[2], f[3]);
+  inside = !((ma < a) | (ma > a)) & !((mb < b) | (mb > b));
+}
+__device__ __forceinline__ void six_search(const float* t, const bool* inside, bool lane_on, float t0, float& loc_t, int& loc_k) {
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    const float mt = __builtin_amdgcn_fmed3f(t[i], t0, loc_t);
+    const bool h = inside[i] & !((mt < t[i]) | (mt > t[i])) & lane_on;
+    loc_t = h ? t[i] : loc_t;
+    loc_k = h ? i : loc_k;
+  }
+}
+template <bool STATS>
+__device__ __forceinline__ void box6_two_searches(const ScanNode* __restrict__ scan, int node, int first, bool lane_on, const RayF& r, Hit& b1,
+                                                  Hit& b2, Counters& cnt) {
+  const u32x16 v0 = *(const RT_CONSTANT_AS u32x16*)((const RT_CONSTANT_AS char*)scan + (unsigned)node * 64u + 64u);
+  const u32x2 v1 = *(const RT_CONSTANT_AS u32x2*)((const RT_CONSTANT_AS char*)scan + (unsigned)node * 64u + 128u);
+  float g[18];
+  __builtin_memcpy(&g[0], &v0, 64);
+  __builtin_memcpy(&g[16], &v1, 8);
+  float t[6];
+  bool inside[6];
+  rect_parts<2, 0, 1>(&g[0], g[4], r, t[0], inside[0]);
+  rect_parts<2, 0, 1>(&g[0], g[5], r, t[1], inside[1]);
+  rect_parts<1, 0, 2>(&g[6], g[10], r, t[2], inside[2]);
+  rect_parts<1, 0, 2>(&g[6], g[11], r, t[3], inside[3]);
+  rect_parts<0, 1, 2>(&g[12], g[16], r, t[4], inside[4]);
+  rect_parts<0, 1, 2>(&g[12], g[17], r, t[5], inside[5]);
+  if (STATS) cnt.rect_tests += lane_on ? 12u : 0u;  // (the events of the two searches)
+  const float big = 3.402823466e+38f;
+  float loc_t = big;
+  int loc_k = -1;
+  six_search(t, inside, lane_on, -big, loc_t, loc_k);
+  bool take = (loc_k >= 0) & !(b1.t < loc_t);
+  b1.t = take ? loc_t : b1.t;
+  b1.prim = take ? first + loc_k : b1.prim;
+  // hitable.rs:566 searches on from rec1.t + 0.0001; in fp32 at least from the next float above rec1.t (see scan_range)
+  float t_next = b1.t + 0.0001f;
+  {
+    const int bits = __float_as_int(b1.t);
+    const float up = __int_as_float(bits >= 0 ? bits + 1 : (bits == (int)0x80000000 ? 1 : bits - 1));
+    t_next = t_next > b1.t ? t_next : up;
+  }
+  loc_t = big;
+  loc_k = -1;
+  six_search(t, inside, lane_on, t_next, loc_t, loc_k);
+  take = (loc_k >= 0) & !(b2.t < loc_t);
+  b2.t = take ? loc_t : b2.t;
+  b2.prim = take ? first + loc_k : b2.prim;
+}
+
 __device__ __forceinline__ int wave_min_i32(int v) {
   for (int off = 32; off > 0; off >>= 1) v = min(v, __shfl_xor(v, off, 64));
   return v;
@@ -633,9 +701,10 @@ __device__ __forceinline__ void scan_range(const DevScene& S, int begin, int end
           const bool v2 = on & (h > 0.0f) & (n2 | f2);
           b2.t = v2 ? (n2 ? t_near : t_far) : b2.t;
           b2.prim = v2 ? n.a : -1;
+        } else if (box6) {
+          box6_two_searches<STATS>(S.scan, i, n.a, on, q, b1, b2, cnt);
         } else {
-          if (box6) box6_test<STATS>(S.scan, i, n.a, on, q, -3.402823466e+38f, 3.402823466e+38f, b1, cnt);
-          else list_test<STATS>(S.prims, n.a, n_boundary, on, q, -3.402823466e+38f, 3.402823466e+38f, b1, cnt);
+          list_test<STATS>(S.prims, n.a, n_boundary, on, q, -3.402823466e+38f, 3.402823466e+38f, b1, cnt);
           // hitable.rs:566 searches on from rec1.t + 0.0001.  Not in the reference, which works in f64: beyond t = 2048 that
           // sum is rec1.t itself in fp32 and a rect (whose test accepts t == t_min) would be found again, so the search
           // starts at the next float above rec1.t at least.
@@ -645,8 +714,7 @@ __device__ __forceinline__ void scan_range(const DevScene& S, int begin, int end
             const float up = __int_as_float(bits >= 0 ? bits + 1 : (bits == (int)0x80000000 ? 1 : bits - 1));
             t_next = t_next > b1.t ? t_next : up;
           }
-          if (box6) box6_test<STATS>(S.scan, i, n.a, on, q, t_next, 3.402823466e+38f, b2, cnt);
-          else list_test<STATS>(S.prims, n.a, n_boundary, on, q, t_next, 3.402823466e+38f, b2, cnt);
+          list_test<STATS>(S.prims, n.a, n_boundary, on, q, t_next, 3.402823466e+38f, b2, cnt);
         }
         float t1 = b1.t, t2 = b2.t;
         t1 = t1 < t_min ? t_min : t1;
