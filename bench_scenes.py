@@ -185,7 +185,7 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     from raytracing_amd import Renderer, Scene, make_params
-    from raytracing_amd.distributed import reduce_to_root, shard_params
+    from raytracing_amd.distributed import TileGather, reduce_to_root, shard_params
     from bench import VALU_PEAK_TFLOPS, HBM_PEAK_GBS, algorithmic_flops
     t0 = time.perf_counter()
     sc = Scene(0x5EED0000)
@@ -221,6 +221,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    gather_dev = gather_host = None
+    if n_ranks > 1 and args.shard == "tiles":
+        if args.rehearse_on_one_gpu:
+            gather_host = TileGather(args.nx, args.ny)
+        else:
+            gather_dev = TileGather(args.nx, args.ny, device=dev)
     prod_ms = None   # this rank's kernel, best of the repetitions
     job_ms = None    # kernel + exchange, slowest rank, best of the repetitions
     for _ in range(args.reps + 1):
@@ -231,10 +237,16 @@ def main():
         r.render_device(cam, p, buf.data_ptr(), None, stream.cuda_stream)
         e1.record(stream)
         if n_ranks > 1:
+            # sample ranges are summed; tile shards are gathered (each rank sends its own pixels only)
             if args.rehearse_on_one_gpu:
                 host = buf.cpu()
-                reduce_to_root(host)
+                if args.shard == "tiles":
+                    gather_host.gather(host)
+                else:
+                    reduce_to_root(host)
                 buf.copy_(host)
+            elif args.shard == "tiles":
+                gather_dev.gather(buf)
             else:
                 reduce_to_root(buf)
         fence()
@@ -276,7 +288,7 @@ def main():
         "Mpaths_per_s": round(paths / t_ms / 1e3, 2), "Mrays_per_s": round(rays / t_ms / 1e3, 2),
         "rays_per_path": round(rays / float(paths), 3), "node_tests_per_ray": round(node_tests / rays, 2),
         "roofline": roofline,
-        "note": "one GPU: the production kernel by HIP events; several: kernel + reduce, slowest rank, wall clock between barriers; "
+        "note": "one GPU: the production kernel by HIP events; several: kernel + exchange (sum of sample ranges, gather of tile shards), slowest rank, wall clock between barriers; "
                 "kernel_ms is rank 0's kernel; the event counts come from a separate launch of the counting build",
     }
     if args.cpu_spp > 0:

@@ -8,7 +8,10 @@ at ns/8 samples and summing the 8 images under a mutex (src/main.rs:74-78,
 threads, and `reduce_to_root` is the sum.  `mode="tiles"` gives each rank a
 disjoint set of 8x8 pixel tiles at the full sample count instead (dealt as
 include/rt_abi.h describes; `shard_width` and `shard_tile_mask` restate it); the
-other ranks leave those pixels zero, so the same sum gathers the image.
+other ranks leave those pixels zero.  `TileGather` then moves each rank's own
+pixels to the root and nothing else (nx*ny*12/N bytes per rank, no arithmetic);
+summing the frames with `reduce_to_root` gives the same image at N times the
+bytes.
 
 Because every (pixel, sample) has its own Philox counter, the result does not
 depend on how the work was split, only on fp32 summation order.
@@ -72,3 +75,60 @@ def reduce_to_root(tensor, group=None, root=0):
     if dist.is_initialized() and dist.get_world_size(group) > 1:
         dist.reduce(tensor, dst=root, op=dist.ReduceOp.SUM, group=group)
     return tensor
+
+
+class TileGather:
+    """The exchange of mode "tiles": every rank packs the pixels of its own tiles,
+    one `gather` moves the packed buffers to the root, the root writes them into
+    its frame.  A rank sends nx*ny*12/N bytes (padded to the largest shard)
+    instead of the whole frame a sum would move, and the root adds nothing, so
+    the gathered image equals the shards bit for bit.  Built once per image
+    size; `gather(frame)` is the per-image call."""
+
+    def __init__(self, nx, ny, device=None, group=None, root=0):
+        import torch
+        import torch.distributed as dist
+        self.group, self.root = group, root
+        self.on = dist.is_initialized() and dist.get_world_size(group) > 1
+        self.rank = dist.get_rank(group) if self.on else 0
+        self.world = dist.get_world_size(group) if self.on else 1
+        self.nx, self.ny = nx, ny
+        if not self.on:
+            return
+
+        def index_of(r):
+            m = torch.from_numpy(shard_tile_mask(nx, ny, r, self.world).reshape(-1))
+            return m.nonzero(as_tuple=False).squeeze(1).to(device)
+        # every rank can count every shard's pixels: the dealing is arithmetic on tile numbers
+        w = shard_width(nx, self.world)
+        import numpy as np
+        ty, tx = np.meshgrid(np.arange((ny + 7) // 8), np.arange((nx + 7) // 8), indexing="ij")
+        owner = (ty * w + tx) % self.world
+        hgt = np.minimum(8, ny - 8 * ty)
+        wid = np.minimum(8, nx - 8 * tx)
+        self.counts = [int((hgt * wid)[owner == r].sum()) for r in range(self.world)]
+        self.pad = max(self.counts)
+        ranks = range(self.world) if self.rank == root else [self.rank]
+        self.index = {r: index_of(r) for r in ranks}
+        self.send = torch.zeros((self.pad, 3), dtype=torch.float32, device=device)
+        self.recv = [torch.empty((self.pad, 3), dtype=torch.float32, device=device) for _ in range(self.world)] if self.rank == root else None
+
+    def bytes_sent_per_rank(self):
+        return self.pad * 12 if self.on else 0
+
+    def gather(self, frame):
+        """`frame`: this rank's float32 sums, ny*nx*3 values, rows from the top (what
+        rt_render_device wrote).  On return the root's frame holds every rank's tiles."""
+        if not self.on:
+            return frame
+        import torch.distributed as dist
+        px = frame.view(-1, 3)
+        if px.shape[0] != self.nx * self.ny:
+            raise ValueError("frame is not ny*nx*3 values")
+        self.send[: self.counts[self.rank]] = px[self.index[self.rank]]
+        dist.gather(self.send, self.recv, dst=self.root, group=self.group)
+        if self.rank == self.root:
+            for r in range(self.world):
+                if r != self.root:
+                    px[self.index[r]] = self.recv[r][: self.counts[r]]
+        return frame

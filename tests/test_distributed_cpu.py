@@ -23,7 +23,7 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, mode, out_path):
+def _worker(rank, world, port, mode, out_path, nx=96, ny=72):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -32,13 +32,18 @@ def _worker(rank, world, port, mode, out_path):
     from conftest import CornellFixture
     from oracle import binding as orc
     from raytracing_amd import make_params
-    from raytracing_amd.distributed import reduce_to_root, shard_params
+    from raytracing_amd.distributed import TileGather, reduce_to_root, shard_params
     c = CornellFixture()
-    params = make_params(96, 72, 10, seed=21)
-    mine = shard_params(params, rank, world, mode)
+    params = make_params(nx, ny, 10, seed=21)
+    mine = shard_params(params, rank, world, "tiles" if mode == "tiles_gather" else mode)
     s, _ = orc.render(c.flat, c.camera.c, mine, mode=orc.ORC_F32_FUSED, n_threads=2)
     t = torch.from_numpy(np.ascontiguousarray(s, dtype=np.float32))
-    reduce_to_root(t)
+    if mode == "tiles_gather":
+        g = TileGather(nx, ny)
+        assert g.bytes_sent_per_rank() < nx * ny * 12 * 0.55  # about half a frame each, not a whole one
+        g.gather(t.view(-1))
+    else:
+        reduce_to_root(t)
     if rank == 0:
         np.save(out_path, t.numpy())
     dist.barrier()
@@ -54,6 +59,22 @@ def test_two_ranks_reproduce_the_single_rank_image(tmp_path, orc, cornell, mode)
     whole, _ = orc.render(cornell.flat, cornell.camera.c, make_params(96, 72, 10, seed=21), mode=orc.ORC_F32_FUSED, n_threads=4)
     assert got.shape == (72, 96, 3)
     assert np.allclose(got, whole.astype(np.float32), rtol=1e-5, atol=1e-5)
+    assert got.sum() > 0
+
+
+@pytest.mark.parametrize("world,nx,ny", [(2, 96, 72), (3, 100, 50)])
+def test_tile_shards_gathered_to_the_root_are_the_single_rank_image(tmp_path, orc, cornell, world, nx, ny):
+    """Mode "tiles" with the gather instead of the sum: each rank sends its own
+    pixels only, and the root's frame is then the one-rank image bit for bit
+    (nothing is added).  The second case has ragged tiles at both edges and a
+    shard count that shares no factor with the 13 tiles of a row."""
+    from raytracing_amd import make_params
+    out = str(tmp_path / "gathered.npy")
+    mp.spawn(_worker, args=(world, _free_port(), "tiles_gather", out, nx, ny), nprocs=world, join=True)
+    got = np.load(out)
+    whole, _ = orc.render(cornell.flat, cornell.camera.c, make_params(nx, ny, 10, seed=21), mode=orc.ORC_F32_FUSED, n_threads=4)
+    assert got.shape == (ny, nx, 3)
+    assert np.array_equal(got, whole.astype(np.float32))
     assert got.sum() > 0
 
 
