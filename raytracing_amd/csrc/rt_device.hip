@@ -297,8 +297,9 @@ __device__ __forceinline__ U4 philox4x32_10(unsigned c0, unsigned c1, unsigned c
   for (int round = 0; round < 10; ++round) {
     const unsigned long long p0 = (unsigned long long)M0 * c0;
     const unsigned long long p1 = (unsigned long long)M1 * c2;
-    const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0;
-    const unsigned n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1;
+    // one three-input XOR each (v_bitop3_b32 with truth table 0x96; the compiler leaves a ^ b ^ c as two instructions)
+    const unsigned n0 = __builtin_amdgcn_bitop3_b32((unsigned)(p1 >> 32), c1, k0, 0x96);
+    const unsigned n2 = __builtin_amdgcn_bitop3_b32((unsigned)(p0 >> 32), c3, k1, 0x96);
     c1 = (unsigned)p1;
     c3 = (unsigned)p0;
     c0 = n0;
@@ -457,9 +458,10 @@ __device__ __forceinline__ bool sphere_test(const float* f, const RayF& r, float
 // closest_so_far starts at t_max; its winner then meets the running best under
 // BvhNode::hit's rule (bvh.rs:212-217): the earlier hit survives only if it is
 // strictly nearer.
+// The list's winner as a candidate for the caller's running best: `take` says whether it replaces it.
 template <bool STATS>
-__device__ __forceinline__ void list_test(const rt_prim* __restrict__ prims, int first, int count, bool lane_on, const RayF& r,
-                                          float t_min, float t_max, Hit& best, Counters& cnt) {
+__device__ __forceinline__ void list_cand(const rt_prim* __restrict__ prims, int first, int count, bool lane_on, const RayF& r,
+                                          float t_min, float t_max, float best_t, float& cand_t, int& cand_prim, bool& take, Counters& cnt) {
   float loc_t = t_max;
   int loc_prim = -1;
   for (int qi = first; qi < first + count; ++qi) {
@@ -480,9 +482,19 @@ __device__ __forceinline__ void list_test(const rt_prim* __restrict__ prims, int
     loc_t = h ? t : loc_t;
     loc_prim = h ? qu : loc_prim;
   }
-  const bool take = (loc_prim >= 0) & !(best.t < loc_t);
-  best.t = take ? loc_t : best.t;
-  best.prim = take ? loc_prim : best.prim;
+  take = (loc_prim >= 0) & !(best_t < loc_t);
+  cand_t = loc_t;
+  cand_prim = loc_prim;
+}
+template <bool STATS>
+__device__ __forceinline__ void list_test(const rt_prim* __restrict__ prims, int first, int count, bool lane_on, const RayF& r,
+                                          float t_min, float t_max, Hit& best, Counters& cnt) {
+  float ct;
+  int cp;
+  bool take;
+  list_cand<STATS>(prims, first, count, lane_on, r, t_min, t_max, best.t, ct, cp, take, cnt);
+  best.t = take ? ct : best.t;
+  best.prim = take ? cp : best.prim;
 }
 
 // A HitableList of exactly six rects in the order Cuboid::new builds them
@@ -507,8 +519,8 @@ __device__ __forceinline__ void box_pair(const float* g, int k, bool lane_on, co
   loc_k = h ? k + 1 : loc_k;
 }
 template <bool STATS>
-__device__ __forceinline__ void box6_test(const ScanNode* __restrict__ scan, int node, int first, bool lane_on, const RayF& r, float t_min,
-                                          float t_max, Hit& best, Counters& cnt) {
+__device__ __forceinline__ void box6_cand(const ScanNode* __restrict__ scan, int node, int first, bool lane_on, const RayF& r, float t_min,
+                                          float t_max, float best_t, float& cand_t, int& cand_prim, bool& take, Counters& cnt) {
   const u32x16 v0 = *(const RT_CONSTANT_AS u32x16*)((const RT_CONSTANT_AS char*)scan + (unsigned)node * 64u + 64u);
   const u32x2 v1 = *(const RT_CONSTANT_AS u32x2*)((const RT_CONSTANT_AS char*)scan + (unsigned)node * 64u + 128u);
   float g[18];
@@ -520,9 +532,19 @@ __device__ __forceinline__ void box6_test(const ScanNode* __restrict__ scan, int
   box_pair<1, 0, 2>(&g[6], 2, lane_on, r, t_min, loc_t, loc_k);
   box_pair<0, 1, 2>(&g[12], 4, lane_on, r, t_min, loc_t, loc_k);
   if (STATS) cnt.rect_tests += lane_on ? 6u : 0u;
-  const bool take = (loc_k >= 0) & !(best.t < loc_t);
-  best.t = take ? loc_t : best.t;
-  best.prim = take ? first + loc_k : best.prim;
+  take = (loc_k >= 0) & !(best_t < loc_t);
+  cand_t = loc_t;
+  cand_prim = first + loc_k;
+}
+template <bool STATS>
+__device__ __forceinline__ void box6_test(const ScanNode* __restrict__ scan, int node, int first, bool lane_on, const RayF& r, float t_min,
+                                          float t_max, Hit& best, Counters& cnt) {
+  float ct;
+  int cp;
+  bool take;
+  box6_cand<STATS>(scan, node, first, lane_on, r, t_min, t_max, best.t, ct, cp, take, cnt);
+  best.t = take ? ct : best.t;
+  best.prim = take ? cp : best.prim;
 }
 
 // The two boundary searches of ConstantMedium::hit (hitable.rs:562-566) over a Cuboid's six rects in one pass: a
@@ -627,8 +649,16 @@ __device__ __forceinline__ void scan_range(const DevScene& S, int begin, int end
     // cuboid's own box (hitable.rs:398-399), where that shortcut is not exact.
     const bool on = DEFER ? act : (act & slab_test(n, r, sg, t_min, t_max, FLAT ? 3.402823466e+38f : best.t));
     if (STATS && !DEFER) cnt.node_tests += act;
+    // Without box tests every lane of the scan has the same `on`, the caller's `active`, and the caller masks the result
+    // with it again (trace_scan's `got`): the primitive tests then run unmasked, which saves a mask operation per test.
+    const bool on_t = (DEFER && !STATS) ? true : on;
     if (!FLAT) lane_next = (act & !on) ? n.skip : lane_next;
     const int kind = n.kind;
+    // Every kind of leaf hands its winner to one update of the running best at the end of the trip (`take`: it replaces
+    // the best so far), so the best hit lives in one pair of registers around the whole loop.
+    float cand_t = 0.0f;
+    int cand_prim = -1;
+    bool take = false;
     if (kind >= K_RECT_XY && kind <= K_RECT_YZ) {
       // A single rect: its own t_max test against the running best is the tie rule.
       float t;
@@ -636,21 +666,23 @@ __device__ __forceinline__ void scan_range(const DevScene& S, int begin, int end
       if (kind == K_RECT_XY) h = rect_test<2, 0, 1>(n.f, r, t_min, best.t, t);
       else if (kind == K_RECT_XZ) h = rect_test<1, 0, 2>(n.f, r, t_min, best.t, t);
       else h = rect_test<0, 1, 2>(n.f, r, t_min, best.t, t);
-      h &= on;
+      h &= on_t;
       if (STATS) cnt.rect_tests += on;
-      best.t = h ? t : best.t;
-      best.prim = h ? n.a : best.prim;
+      take = h;
+      cand_t = t;
+      cand_prim = n.a;
     } else if (kind == K_SPHERE) {
       float t;
-      bool h = sphere_test(n.f, r, t_min, t_max, t) & on;
+      bool h = sphere_test(n.f, r, t_min, t_max, t) & on_t;
       if (STATS) cnt.sphere_tests += on;
       h &= !(best.t < t);
-      best.t = h ? t : best.t;
-      best.prim = h ? n.a : best.prim;
+      take = h;
+      cand_t = t;
+      cand_prim = n.a;
     } else if (kind == K_LIST) {
       if (__ballot(on) != 0ull) {
-        if (n.b & LIST_IS_BOX6) box6_test<STATS>(S.scan, i, n.a, on, r, t_min, t_max, best, cnt);
-        else list_test<STATS>(S.prims, n.a, n.b & 0x7fffff, on, r, t_min, t_max, best, cnt);
+        if (n.b & LIST_IS_BOX6) box6_cand<STATS>(S.scan, i, n.a, on_t, r, t_min, t_max, best.t, cand_t, cand_prim, take, cnt);
+        else list_cand<STATS>(S.prims, n.a, n.b & 0x7fffff, on_t, r, t_min, t_max, best.t, cand_t, cand_prim, take, cnt);
       }
     } else if (kind == K_OBJ_LIST || kind == K_OBJ_BVH) {
       if (LEVEL == 0) {
@@ -658,8 +690,8 @@ __device__ __forceinline__ void scan_range(const DevScene& S, int begin, int end
           const RayF q = to_object_frame<true, true>(r, n.b >> 24, n.f[0], n.f[1], n.f[2], n.f[3], n.f[4]);
           if (STATS) cnt.instance_ops += on;
           if (kind == K_OBJ_LIST) {
-            if (n.b & LIST_IS_BOX6) box6_test<STATS>(S.scan, i, n.a, on, q, t_min, t_max, best, cnt);
-            else list_test<STATS>(S.prims, n.a, n.b & 0x7fffff, on, q, t_min, t_max, best, cnt);
+            if (n.b & LIST_IS_BOX6) box6_cand<STATS>(S.scan, i, n.a, on_t, q, t_min, t_max, best.t, cand_t, cand_prim, take, cnt);
+            else list_cand<STATS>(S.prims, n.a, n.b & 0x7fffff, on_t, q, t_min, t_max, best.t, cand_t, cand_prim, take, cnt);
           }
           else if (!FLAT) scan_range<STATS, false, false, 1>(S, i + 1, n.skip, on, q, t_min, t_max, rng, best, cnt);
         }
@@ -734,6 +766,8 @@ __device__ __forceinline__ void scan_range(const DevScene& S, int begin, int end
         }
       }
     }
+    best.t = take ? cand_t : best.t;
+    best.prim = take ? cand_prim : best.prim;
     // A leaf's skip is the next node (past any extension slots); an interior node's first child follows it.
     i = (kind == K_INTERIOR) ? i + 1 : n.skip;
   }
@@ -3186,6 +3220,7 @@ int launch_render(rt_ctx* ctx, const rt_camera* cam, const rt_render_params* p, 
   // One wave for every slot a CU has (8 per SIMD); where the kernel's registers allow fewer, the rest
   // start when the first waves are done, find no item left and leave.  Never more waves than items.
   long long waves = 32LL * (ctx->n_cus > 0 ? ctx->n_cus : 1);
+  if (const char* e = getenv("RT_WAVES_PER_CU")) waves = (long long)(atoi(e) > 0 ? atoi(e) : 32) * (ctx->n_cus > 0 ? ctx->n_cus : 1);  // tuning
   if (waves > n_items) waves = n_items;
   // The stack kernel keeps the first entries of a lane's stack in LDS (what decides how many waves a CU holds) and
   // the rest of the scene's worst case in global memory, one region per wave of the grid.
