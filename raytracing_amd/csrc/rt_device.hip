@@ -620,6 +620,50 @@ __device__ __forceinline__ int wave_min_i32(int v) {
   return v;
 }
 
+// The deferred scan of a flat array that leaves media out (the Cornell box; rt_trace_closest): every slot it tests is a
+// single rect, a single sphere, a list or a list under Translate/RotateY, so the loop needs none of scan_range's bookkeeping for skipping lanes,
+// sub-trees and media.  Scalar instructions take the same issue slots as vector ones (tools/probe_valu.sh), and
+// the general loop spends about 25 of them per leaf on its dispatch.  Same tests in the same order as scan_range.
+template <bool STATS>
+__device__ __forceinline__ void scan_flat_lean(const DevScene& S, int end, bool active, const RayF& r, float t_min, float t_max, Hit& best,
+                                               Counters& cnt) {
+  const bool on_t = STATS ? active : true;  // the caller masks the result with `active` (trace_scan's `got`)
+  if (end <= 0) return;
+  int i = 0;
+  do {
+    const ScanNode n = load_node(S.scan, i);
+    const int kind = n.kind;
+    float cand_t = 0.0f;
+    int cand_prim = -1;
+    bool take = false;
+    if (kind <= K_RECT_YZ) {
+      // A single rect: its own t_max test against the running best is the tie rule.
+      if (kind == K_RECT_XY) take = rect_test<2, 0, 1>(n.f, r, t_min, best.t, cand_t);
+      else if (kind == K_RECT_XZ) take = rect_test<1, 0, 2>(n.f, r, t_min, best.t, cand_t);
+      else take = rect_test<0, 1, 2>(n.f, r, t_min, best.t, cand_t);
+      take &= on_t;
+      if (STATS) cnt.rect_tests += active;
+      cand_prim = n.a;
+    } else if (kind == K_SPHERE) {
+      take = sphere_test(n.f, r, t_min, t_max, cand_t) & on_t;
+      if (STATS) cnt.sphere_tests += active;
+      take &= !(best.t < cand_t);
+      cand_prim = n.a;
+    } else if (kind == K_LIST) {
+      if (n.b & LIST_IS_BOX6) box6_cand<STATS>(S.scan, i, n.a, on_t, r, t_min, t_max, best.t, cand_t, cand_prim, take, cnt);
+      else list_cand<STATS>(S.prims, n.a, n.b & 0x7fffff, on_t, r, t_min, t_max, best.t, cand_t, cand_prim, take, cnt);
+    } else if (kind == K_OBJ_LIST) {  // (what is left is a ConstantMedium in a query that leaves media out: rt_trace_closest)
+      const RayF q = to_object_frame<true, true>(r, n.b >> 24, n.f[0], n.f[1], n.f[2], n.f[3], n.f[4]);
+      if (STATS) cnt.instance_ops += active;
+      if (n.b & LIST_IS_BOX6) box6_cand<STATS>(S.scan, i, n.a, on_t, q, t_min, t_max, best.t, cand_t, cand_prim, take, cnt);
+      else list_cand<STATS>(S.prims, n.a, n.b & 0x7fffff, on_t, q, t_min, t_max, best.t, cand_t, cand_prim, take, cnt);
+    }
+    best.t = take ? cand_t : best.t;
+    best.prim = take ? cand_prim : best.prim;
+    i = n.skip;
+  } while (i < end);
+}
+
 // Walks scan[begin, end) for the lanes with active == true, all 64 lanes of the
 // wave taking part in the control flow.  LEVEL 0 is the world frame; a K_OBJ_BVH
 // node re-enters at LEVEL 1 with the ray moved into the object's frame.  FLAT
@@ -1055,7 +1099,8 @@ __device__ __forceinline__ Hit trace_scan(const DevScene& S, unsigned* stk, cons
     // winner among the box-tested candidates, each of which is one of the
     // candidates it beat.  If it fails for any lane, the wave redoes the scan
     // with every box test in place.
-    scan_range<STATS, true, MEDIA, 0, true>(S, 0, S.n_scan, active, w, t_min, t_max, rng, best, cnt);
+    if (!MEDIA) scan_flat_lean<STATS>(S, S.n_scan, active, w, t_min, t_max, best, cnt);
+    else scan_range<STATS, true, MEDIA, 0, true>(S, 0, S.n_scan, active, w, t_min, t_max, rng, best, cnt);
     const bool got = active & (best.prim >= 0);
     const float4* lb = leaf_box + 2 * (got ? best.prim : 0);
     const float4 b0 = lb[0], b1 = lb[1];
@@ -1902,6 +1947,24 @@ __global__ void __launch_bounds__(64, (TRAV == TRAV_STACK && GENERAL < 2) ? 6 : 
       fresh = false;
     }
     const RayF ray = make_ray(ro, rd);
+#ifdef RT_PROBE
+    // Diagnostic build (-DRT_PROBE=k, tools/probe_valu.sh): 50 more instructions of one kind in every trip of the path
+    // loop, results unused (depth comes back unchanged).  How much the launch slows down per added instruction says
+    // what bounds the kernel: a unit with slack absorbs them.  No probe exists in the normal build.
+#if RT_PROBE == 1
+    asm volatile(".rept 50\n s_nop 0\n .endr\n");
+#elif RT_PROBE == 2
+    { int tmp_ = depth; asm volatile(".rept 50\n v_xor_b32 %0, 1, %0\n .endr\n" : "+v"(tmp_)); depth = tmp_; }
+#elif RT_PROBE == 3
+    { int tmp_ = depth; asm volatile(".rept 50\n v_cmp_lt_i32 vcc, 1, %0\n .endr\n" : "+v"(tmp_) : : "vcc"); depth = tmp_; }
+#elif RT_PROBE == 4
+    { int tmp_ = depth; asm volatile("v_cmp_lt_i32 vcc, 1000, %0\n .rept 50\n v_cndmask_b32 %0, %0, %0, vcc\n .endr\n" : "+v"(tmp_) : : "vcc"); depth = tmp_; }
+#elif RT_PROBE == 5
+    { float tmp_ = __int_as_float(depth); asm volatile(".rept 50\n v_med3_f32 %0, %0, %0, %0\n .endr\n" : "+v"(tmp_)); depth = __float_as_int(tmp_); }
+#elif RT_PROBE == 6
+    { int tmp_ = depth; asm volatile(".rept 50\n s_and_b64 vcc, vcc, exec\n .endr\n" : "+v"(tmp_) : : "vcc"); depth = tmp_; }
+#endif
+#endif
 
     // ---- world.hit(r, 0.001, INFINITY), main.rs:166 ----
     if (STATS) cnt.rays += alive;
