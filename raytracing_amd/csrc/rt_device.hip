@@ -901,6 +901,7 @@ typedef __attribute__((address_space(3))) unsigned lds_u32;
 typedef __attribute__((address_space(1))) unsigned glb_u32;
 template <bool OVF>
 struct LaneStackT {
+  static constexpr bool kOvf = OVF;
   lds_u32* lds;  // this lane's column: entry `at` is the pair lds[at * 128] (reference), lds[at * 128 + 64] (distance key)
   int n_lds;     // entries in LDS
   glb_u32* ovf;  // this lane's column of the wave's overflow region, same layout (OVF only)
@@ -946,7 +947,7 @@ __device__ __forceinline__ int trav_enter(const DevScene& S, int ref, int box, c
 // when the walk has ended.  (Leaves, single primitives included, are left to trav_leaf: the wave runs that code for
 // many lanes at once, which was measured faster than testing a primitive where a lane meets it.)
 template <bool STATS, class STK>
-__device__ __forceinline__ bool trav_step(const DevScene& S, STK& stk, Trav& T, float t_min, float t_max, Counters& cnt) {
+__device__ __forceinline__ bool trav_step_impl(const DevScene& S, STK& stk, Trav& T, float t_min, float t_max, Counters& cnt) {
   if (T.cur == TRAV_POP) {
     // Entries wait on the stack with their pruning distance (the sort key of the step that pushed them: the distance
     // rounded down by its two lowest bits): what has been found since may lie nearer than an entry's box begins,
@@ -1002,6 +1003,23 @@ __device__ __forceinline__ bool trav_step(const DevScene& S, STK& stk, Trav& T, 
   T.cur = n_hit >= 1 ? RT_REF_OF(k0) : TRAV_POP;
 #undef RT_REF_OF
   return true;
+}
+
+// A stack with a global part decides at every access which part an entry lives in, a branch around each of a step's
+// five accesses.  Walks seldom leave the LDS part, so the wave first asks whether any of its stepping lanes could (a
+// step pops one entry or pushes three at most): if none can, the step runs on a view of the stack that has no global part.
+template <bool STATS, class STK>
+__device__ __forceinline__ bool trav_step(const DevScene& S, STK& stk, Trav& T, float t_min, float t_max, Counters& cnt) {
+  if (STK::kOvf) {
+    if (__ballot(T.sp + 3 > stk.n_lds) == 0ull) {
+      LaneStackT<false> in_lds;
+      in_lds.lds = stk.lds;
+      in_lds.n_lds = stk.n_lds;
+      in_lds.ovf = nullptr;
+      return trav_step_impl<STATS>(S, in_lds, T, t_min, t_max, cnt);
+    }
+  }
+  return trav_step_impl<STATS>(S, stk, T, t_min, t_max, cnt);
 }
 
 // The leaf a lane holds (its box has been passed): a primitive list in the current frame, or an object:
