@@ -28,6 +28,8 @@ v={k:min(x) for k,x in c.items()}
 for k in sorted(v): print("  %-24s %.5g" % (k, v[k]))
 cyc=v['GRBM_GUI_ACTIVE']/8
 print("VALU instructions per SIMD-cycle: %.3f of 0.5" % (v['SQ_INSTS_VALU']/(1024*cyc)))
+alli = v['SQ_INSTS_VALU'] + v['SQ_INSTS_SALU'] + v['SQ_INSTS_SMEM'] + v['SQ_INSTS_LDS'] + v['SQ_INSTS_VMEM_RD']
+print("vector + scalar + memory instructions per SIMD-cycle: %.3f (the flat kernel saturates at 0.5)" % (alli/(1024*cyc)))
 print("lane utilisation: %.3f" % (v['SQ_THREAD_CYCLES_VALU']/(v['SQ_ACTIVE_INST_VALU']*4*64/4)/1.0 if False else v['SQ_THREAD_CYCLES_VALU']/(v['SQ_INSTS_VALU']*64)))
 w=v['SQ_WAVE_CYCLES']
 print("wave time: issuing %.3f, parked on a counter %.3f, waiting to issue %.3f" % (v['SQ_ACTIVE_INST_ANY']/w, v['SQ_WAIT_ANY']/w, v['SQ_WAIT_INST_ANY']/w))
