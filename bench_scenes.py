@@ -258,6 +258,20 @@ def main():
         ms = e0.elapsed_time(e1)
         prod_ms = ms if prod_ms is None else min(prod_ms, ms)
         job_ms = dt * 1e3 if job_ms is None else min(job_ms, dt * 1e3)
+    # The rehearsal's image check: the root's frame after the exchange against the whole image rendered by the root alone
+    # (tile shards: the same samples of the same pixels, equal to fp32 summation order of the kernel's own accumulation;
+    # sample ranges: to the order in which the ranks' sums are added).
+    image_check = None
+    if n_ranks > 1 and args.rehearse_on_one_gpu and rank == 0:
+        whole = torch.empty_like(buf)
+        r.render_device(cam, make_params(args.nx, args.ny, args.spp, sky=sky), whole.data_ptr(), None, stream.cuda_stream)
+        torch.cuda.synchronize(dev)
+        diff = (buf - whole).abs()
+        tol = 1e-5 * whole.abs() + 1e-5
+        image_check = {"max_abs_diff": float(diff.max().item()), "values_beyond_fp32_order": int((diff > tol).sum().item()),
+                       "values": int(whole.numel()), "sum": float(whole.double().sum().item())}
+        if image_check["values_beyond_fp32_order"] > 0:
+            raise SystemExit("rehearsal: the exchanged frame differs from the one-rank image: %r" % (image_check,))
     # totals over the ranks of the event counts (each rank counted its own share)
     rays, node_tests, flops = float(best.rays), float(best.node_tests), float(algorithmic_flops(best))
     sphere_tests = float(best.sphere_tests)
@@ -291,6 +305,8 @@ def main():
         "note": "one GPU: the production kernel by HIP events; several: kernel + exchange (sum of sample ranges, gather of tile shards), slowest rank, wall clock between barriers; "
                 "kernel_ms is rank 0's kernel; the event counts come from a separate launch of the counting build",
     }
+    if image_check is not None:
+        line["rehearsal_image_check"] = image_check
     if args.cpu_spp > 0:
         from oracle import binding as orc
         cp = make_params(args.nx, args.ny, args.cpu_spp, sky=sky)

@@ -8,4 +8,12 @@ L="python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 1
 run python bench_scenes.py --scene final --nx 1920 --ny 1080 --spp 64
 run $L --master-port 29512 bench_scenes.py --gpus 2 --shard tiles --rehearse-on-one-gpu --scene final --nx 1920 --ny 1080 --spp 64
 run $L --master-port 29513 bench_scenes.py --gpus 2 --shard samples --rehearse-on-one-gpu --scene stress --spheres 65536 --nx 640 --ny 360 --spp 16
-cut -c1-700 gpurun_out/rehearse_scenes.jsonl
+run $L --master-port 29514 bench_scenes.py --gpus 2 --shard tiles --rehearse-on-one-gpu --scene smoke --nx 1000 --ny 700 --spp 16
+L3="python -m torch.distributed.run --nnodes=1 --nproc-per-node 3 --master-addr 127.0.0.1"
+run $L3 --master-port 29515 bench_scenes.py --gpus 3 --shard tiles --rehearse-on-one-gpu --scene cornell --nx 500 --ny 300 --spp 32
+python - <<'PY'
+import json
+for l in open('gpurun_out/rehearse_scenes.jsonl'):
+    d = json.loads(l)
+    print(d['scene'], d['nx'], d['ny'], d['spp'], d['sharding'], 'ms', d['ms_per_image'], 'image check', d.get('rehearsal_image_check'))
+PY
