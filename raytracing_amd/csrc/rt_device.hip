@@ -311,6 +311,30 @@ __device__ __forceinline__ U4 philox4x32_10(unsigned c0, unsigned c1, unsigned c
   r.x = c0; r.y = c1; r.z = c2; r.w = c3;
   return r;
 }
+// The same with the twenty round keys read from LDS (rk[2 * round], rk[2 * round + 1]; every lane reads the same
+// addresses) instead of made by eighteen scalar additions per call: five LDS reads.
+__device__ __forceinline__ U4 philox4x32_10_keys(unsigned c0, unsigned c1, unsigned c2, unsigned c3, const unsigned* rk) {
+  const unsigned M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
+  uint4 kk[5];
+#pragma unroll
+  for (int i = 0; i < 5; ++i) kk[i] = ((const uint4*)rk)[i];
+  unsigned k[20];
+  __builtin_memcpy(k, kk, sizeof(k));
+#pragma unroll
+  for (int round = 0; round < 10; ++round) {
+    const unsigned long long p0 = (unsigned long long)M0 * c0;
+    const unsigned long long p1 = (unsigned long long)M1 * c2;
+    const unsigned n0 = __builtin_amdgcn_bitop3_b32((unsigned)(p1 >> 32), c1, k[2 * round], 0x96);
+    const unsigned n2 = __builtin_amdgcn_bitop3_b32((unsigned)(p0 >> 32), c3, k[2 * round + 1], 0x96);
+    c1 = (unsigned)p1;
+    c3 = (unsigned)p0;
+    c0 = n0;
+    c2 = n2;
+  }
+  U4 r;
+  r.x = c0; r.y = c1; r.z = c2; r.w = c3;
+  return r;
+}
 __device__ __forceinline__ float u01(unsigned x) { return (float)(x >> 8) * (1.0f / 16777216.0f); }
 
 // What a ConstantMedium needs to draw its random number inside the traversal.
@@ -1772,6 +1796,11 @@ __global__ void __launch_bounds__(64, (TRAV == TRAV_STACK && GENERAL < 2) ? 6 : 
   // The camera (19 floats, used once per path) lives in LDS rather than in scalar
   // registers for the life of the kernel; every lane reads the same address.
   __shared__ float cam_lds[20];
+  __shared__ __align__(16) unsigned rk_lds[20];  // Philox's round keys
+  if (lane < 10) {
+    rk_lds[2 * lane] = A.key0 + (unsigned)lane * 0x9E3779B9u;
+    rk_lds[2 * lane + 1] = A.key1 + (unsigned)lane * 0xBB67AE85u;
+  }
   if (lane == 0) {
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
@@ -1926,7 +1955,9 @@ __global__ void __launch_bounds__(64, (TRAV == TRAV_STACK && GENERAL < 2) ? 6 : 
     unsigned key0 = A.key0, key1 = A.key1;
     asm volatile("" : "+s"(key0), "+s"(key1));
     // ---- the one Philox call of this vertex: counter (pixel, sample, depth, 0) ----
-    const U4 w = philox4x32_10(pixel_id, sample, (unsigned)depth, 0u, key0, key1);
+    int rk0 = 0;
+    asm volatile("" : "+v"(rk0));  // (an index the optimiser cannot see through keeps the reads of the keys inside the loop)
+    const U4 w = philox4x32_10_keys(pixel_id, sample, (unsigned)depth, 0u, rk_lds + rk0);
 
     // ---- camera ray of the fresh lanes (main.rs:102-105, camera.rs:53-62) ----
     if (__ballot(fresh) != 0ull) {
