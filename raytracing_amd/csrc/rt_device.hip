@@ -1955,9 +1955,15 @@ __global__ void __launch_bounds__(64, (TRAV == TRAV_STACK && GENERAL < 2) ? 6 : 
     unsigned key0 = A.key0, key1 = A.key1;
     asm volatile("" : "+s"(key0), "+s"(key1));
     // ---- the one Philox call of this vertex: counter (pixel, sample, depth, 0) ----
-    int rk0 = 0;
-    asm volatile("" : "+v"(rk0));  // (an index the optimiser cannot see through keeps the reads of the keys inside the loop)
-    const U4 w = philox4x32_10_keys(pixel_id, sample, (unsigned)depth, 0u, rk_lds + rk0);
+    // (the build for Lambertian scenes only: in the others the twenty registers the keys need for a moment cost spills)
+    U4 w;
+    if (GENERAL == 0) {
+      int rk0 = 0;
+      asm volatile("" : "+v"(rk0));  // (an index the optimiser cannot see through keeps the reads of the keys inside the loop)
+      w = philox4x32_10_keys(pixel_id, sample, (unsigned)depth, 0u, rk_lds + rk0);
+    } else {
+      w = philox4x32_10(pixel_id, sample, (unsigned)depth, 0u, key0, key1);
+    }
 
     // ---- camera ray of the fresh lanes (main.rs:102-105, camera.rs:53-62) ----
     if (__ballot(fresh) != 0ull) {
