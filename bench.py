@@ -56,7 +56,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stats", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true",
-                    help="skip the short runs of the other named configurations (single GPU only; they add about a minute)")
+                    help="skip the runs of the other named configurations (one GPU: short runs of all four, about a minute; "
+                         "several: the final scene by tiles and the 8K smoke frame by sample ranges, a few seconds each)")
+    ap.add_argument("--multi-spp", type=int, default=0,
+                    help="several ranks: samples per pixel of the other configurations' multi-rank runs (default: 4096 for the final "
+                         "scene, 1024 for the 8K smoke frame)")
     ap.add_argument("--no-overlap", action="store_true", help="several ranks: wait for each image's reduce before rendering the next")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="N ranks share GPU 0 and exchange over gloo: checks the multi-rank control flow on a one-GPU box, not a benchmark")
@@ -268,6 +272,20 @@ def main():
                 other.append(measure_config(cfg, device_index=local_rank, cpu=not args.no_cpu_baseline))
             except Exception as e:  # a failed side configuration must not lose the headline line
                 other.append({"config": cfg["name"], "error": "%s: %s" % (type(e).__name__, e)})
+
+    # Several ranks: the two named configurations that are defined on several GPUs (final scene by pixel tiles and a
+    # gather, the 8K smoke frame by sample ranges and a sum), each with its per-rank kernel time, its exchange time and
+    # its efficiency against the whole image rendered by rank 0 alone in the same run.  Every rank takes part.
+    if world > 1 and not args.no_other_configs:
+        from bench_scenes import MULTI_CONFIGS, measure_config_multi
+        other = []
+        for cfg in MULTI_CONFIGS:
+            try:
+                res = measure_config_multi(cfg, rank, world, local_rank, rehearse=args.rehearse_on_one_gpu,
+                                           spp=args.multi_spp if args.multi_spp > 0 else None)
+            except Exception as e:  # (a rank that fails alone leaves the others in a collective: the job's timeout ends that)
+                res = {"config": cfg["name"], "error": "%s: %s" % (type(e).__name__, e)}
+            other.append(res)
 
     if rank == 0:
         paths = float(nx) * ny * spp * args.steps

@@ -259,8 +259,50 @@ const char* rt_last_error(void);
 int rt_create(int device_id, rt_ctx** out);
 int rt_destroy(rt_ctx* ctx);
 
-/* Validates and copies the scene to the device (replaces any previous one). */
+/* Context options.  No counterpart in the reference (its only knobs are constants in
+ * the source, src/main.rs:70,173).  A value outside an option's range is clamped to
+ * it; an unknown option is RT_ERR_INVALID.  Each option's default can also be set
+ * from the environment variable named beside it, which rt_create reads ONCE (and
+ * clamps the same way); no render call reads the environment.
+ *   RT_OPT_FIXED_ORDER (RT_NO_ACCUMULATE; 0 or 1, default 0): scenes on the per-lane
+ *     stack traversal normally add each work item's tile sums into the output with
+ *     hardware float adds, in whatever order the items finish, so the last bits of a
+ *     pixel's sum can differ from run to run.  With 1, every work item writes a
+ *     partial image of its own, a wave has one item open at a time, and the partial
+ *     images are added in a fixed order: equal inputs give equal bits on every run
+ *     (at some cost in speed and up to 1 GiB of partial images).  Scenes of at most
+ *     16 leaves and scenes on the skip-link scan always work that way.
+ *   RT_OPT_READY_LANES (RT_READY_LANES; 1..64, default 0 = chosen per scene): finished
+ *     rays in 64 live lanes that end a traversal phase of the stack kernel.
+ *   RT_OPT_HOLD_LANES (RT_HOLD_LANES; 1..64, default 16): lanes holding a leaf, in 64
+ *     traversing ones, that make the wave run the leaf code.
+ *   RT_OPT_STACK_LDS_ENTRIES (RT_STACK_LDS_CAP; 1..64, default 10): entries of a lane's
+ *     traversal stack kept in LDS; deeper ones live in global memory.
+ *   RT_OPT_WAVES_PER_CU (RT_WAVES_PER_CU; 1..32, default 32): waves launched per CU.
+ *   RT_OPT_ITEM_ROUNDS (RT_WANT_ROUNDS; 1..1000, default 30): work items the launch
+ *     aims for, per wave slot of the chip.
+ *   RT_OPT_MIN_CHUNK_SPP (RT_MIN_CHUNK_SPP; 1..65536, default 0 = chosen per launch):
+ *     fewest samples of a tile that make one work item.
+ *   RT_OPT_LAST_CHUNK_SPP (RT_STACK_LAST_SPP; 1..65536, default 4): the stack kernel's
+ *     last sample chunk of a tile is halved down to parts of this many samples. */
+#define RT_OPT_FIXED_ORDER 1
+#define RT_OPT_READY_LANES 2
+#define RT_OPT_HOLD_LANES 3
+#define RT_OPT_STACK_LDS_ENTRIES 4
+#define RT_OPT_WAVES_PER_CU 5
+#define RT_OPT_ITEM_ROUNDS 6
+#define RT_OPT_MIN_CHUNK_SPP 7
+#define RT_OPT_LAST_CHUNK_SPP 8
+int rt_set_option(rt_ctx* ctx, int option, int value);
+int rt_get_option(const rt_ctx* ctx, int option, int* value_out);
+
+/* Validates and copies the scene to the device (replaces any previous one).
+ * upload_ms_or_null of rt_upload_scene_timed receives the wall time of the call's two
+ * parts: [0] building the device's own views of the tree on the host (the SAH /
+ * four-wide interior over the given leaves, the scan array, per-primitive records),
+ * [1] allocation and copies to the device. */
 int rt_upload_scene(rt_ctx* ctx, const rt_scene* scene);
+int rt_upload_scene_timed(rt_ctx* ctx, const rt_scene* scene, double* upload_ms_or_null);
 
 /* Replaces main.rs:67-133.  Writes per-pixel SUMS (not means) of de_nan'ed
  * sample radiance, nx*ny*3 floats, top row first, x ascending (main.rs:96-97,
@@ -321,17 +363,23 @@ int rt_render_device_noalloc(rt_ctx* ctx, const rt_camera* cam, const rt_render_
  *                     as for rt_render_params.shard_index) at the full sample
  *                     count; each rank sends only its own tiles and rank 0 puts
  *                     them in place: nx*ny*12/N bytes per rank, no arithmetic.
- * With distinct device ids the exchange is RCCL on the ranks' streams (one
- * communicator per rank from ncclCommInitAll; ncclReduce, or grouped
- * ncclSend/ncclRecv); librccl.so is opened when such a context is created.  With
- * repeated ids, or RT_MULTI_NO_RCCL, rank 0's stream copies the other ranks'
- * buffers over and adds or places them in rank order.  Results equal a
+ * With more than one rank and distinct device ids the exchange is RCCL on the
+ * ranks' streams (one communicator per rank from ncclCommInitAll; ncclReduce, or
+ * grouped ncclSend/ncclRecv); librccl.so is opened when such a context is created,
+ * and if it cannot be loaded or initialised the context falls back to the copy
+ * path (rt_multi_uses_rccl() then returns 0).  With repeated ids, one rank, or
+ * RT_MULTI_NO_RCCL, rank 0's stream copies the other ranks' buffers over and adds
+ * or places them in rank order.  The RCCL exchange between DIFFERENT devices has
+ * not run on hardware yet (no multi-GPU machine was available to this build); the
+ * copy path and the one-rank RCCL calls have.  Results equal a
  * one-rank render up to the order of fp32 additions (tile mode: up to how each
  * launch splits a tile's samples into partial sums), because every (pixel,
  * sample) has its own random-number counter.  Not thread-safe. */
 #define RT_SHARD_SAMPLES 0
 #define RT_SHARD_TILES 1
 #define RT_MULTI_NO_RCCL 1u
+#define RT_MULTI_FORCE_RCCL 2u /* RCCL even for a single rank (the calls then run on one GPU: a reduce onto itself,
+                                * an empty send/receive group), and an error instead of the fallback when it cannot be used */
 typedef struct rt_multi rt_multi;
 int rt_multi_create(const int* device_ids, int n_devices, unsigned flags, rt_multi** out);
 int rt_multi_destroy(rt_multi* m);

@@ -27,6 +27,9 @@ RT_SKY_BLACK, RT_SKY_GRADIENT = 0, 1
 RT_SHARD_SAMPLES, RT_SHARD_TILES = 0, 1
 RT_LIGHT_XZ_RECT, RT_LIGHT_XY_RECT, RT_LIGHT_YZ_RECT, RT_LIGHT_SPHERE = 0, 1, 2, 3
 RT_MULTI_NO_RCCL = 1
+RT_MULTI_FORCE_RCCL = 2
+(RT_OPT_FIXED_ORDER, RT_OPT_READY_LANES, RT_OPT_HOLD_LANES, RT_OPT_STACK_LDS_ENTRIES, RT_OPT_WAVES_PER_CU,
+ RT_OPT_ITEM_ROUNDS, RT_OPT_MIN_CHUNK_SPP, RT_OPT_LAST_CHUNK_SPP) = range(1, 9)
 
 
 class rt_node(C.Structure):
@@ -130,7 +133,10 @@ def lib():
     sig("rt_camera_init", C.c_int, C.POINTER(rt_camera), d3, d3, d3, C.c_double, C.c_double, C.c_double, C.c_double)
     sig("rt_create", C.c_int, C.c_int, C.POINTER(vp))
     sig("rt_destroy", C.c_int, vp)
+    sig("rt_set_option", C.c_int, vp, C.c_int, C.c_int)
+    sig("rt_get_option", C.c_int, vp, C.c_int, C.POINTER(C.c_int))
     sig("rt_upload_scene", C.c_int, vp, C.POINTER(rt_scene))
+    sig("rt_upload_scene_timed", C.c_int, vp, C.POINTER(rt_scene), C.POINTER(C.c_double))
     sig("rt_render", C.c_int, vp, C.POINTER(rt_camera), C.POINTER(rt_render_params), vp, vp, C.POINTER(rt_stats))
     sig("rt_render_device", C.c_int, vp, C.POINTER(rt_camera), C.POINTER(rt_render_params), vp, vp, vp)
     sig("rt_render_device_noalloc", C.c_int, vp, C.POINTER(rt_camera), C.POINTER(rt_render_params), vp, vp, vp)

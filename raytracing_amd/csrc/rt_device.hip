@@ -40,6 +40,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -1689,16 +1690,6 @@ __device__ __forceinline__ Shaded shade_vertex(const DevScene& S, const float4* 
       F3 rs = f3(0, 0, 0);
       bool looking = is_metal | is_iso;
       unsigned attempt = 0;
-#ifdef RT_HACK_DIRECT_BALL
-      {
-        const U4 sw = philox4x32_10(pixel_id, sample, (unsigned)depth, 256u + attempt, key0, key1);
-        const float cz = 1.0f - 2.0f * u01(sw.x);
-        const float sz = fast_sqrt(fmaxf(0.0f, 1.0f - cz * cz));
-        const float rad = __builtin_amdgcn_exp2f(__builtin_amdgcn_logf(u01(sw.z)) * (1.0f / 3.0f));
-        rs = f3(rad * sz * __builtin_amdgcn_cosf(u01(sw.y)), rad * sz * __builtin_amdgcn_sinf(u01(sw.y)), rad * cz);
-        looking = false;
-      }
-#endif
       while (__ballot(looking) != 0ull) {
         const U4 sw = philox4x32_10(pixel_id, sample, (unsigned)depth, 256u + attempt, key0, key1);
         const F3 c = f3(2.0f * u01(sw.x) - 1.0f, 2.0f * u01(sw.y) - 1.0f, 2.0f * u01(sw.z) - 1.0f);
@@ -1764,6 +1755,7 @@ struct RenderArgs {
   int ready_lanes;          // render_stack_kernel: finished rays in a wave (in 64 live ones) that end a traversal phase
   int hold_lanes;           // and lanes holding a leaf (in 64 traversing ones) that make the wave run the leaf code
   int accumulate;           // render_stack_kernel: items ADD their tile sums to the (zeroed) output instead of writing partial images
+  int max_slots;            // render_stack_kernel: work items a wave may have open at once (1: a pixel's sum does not depend on scheduling)
   int stack_lds;            // render_stack_kernel: entries of a lane's stack kept in LDS; deeper ones go to stack_ovf
   unsigned* stack_ovf;      // (scene's stack depth - stack_lds) x 128 dwords for every wave of the grid
 };
@@ -2169,7 +2161,8 @@ __global__ void __launch_bounds__(64, GENERAL < 2 ? RT_STACK_WAVES : 5) render_s
   float a_t_min = A.t_min;
   int a_max_depth = A.max_depth, a_sky = A.sky;
   int a_ready = A.ready_lanes, a_hold = A.hold_lanes;
-  asm volatile("" : "+s"(a_t_min), "+s"(a_max_depth), "+s"(a_sky), "+s"(a_ready), "+s"(a_hold));
+  int slots_cap = A.max_slots < RT_SLOTS ? A.max_slots : RT_SLOTS;
+  asm volatile("" : "+s"(a_t_min), "+s"(a_max_depth), "+s"(a_sky), "+s"(a_ready), "+s"(a_hold), "+s"(slots_cap));
 #ifdef RT_PHASE_TIMING
   unsigned long long ph[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long t_last = __builtin_amdgcn_s_memtime();
@@ -2318,7 +2311,7 @@ __global__ void __launch_bounds__(64, GENERAL < 2 ? RT_STACK_WAVES : 5) render_s
           }
           open_mask &= ~(1u << d);
         }
-        if (!fill_open && !queue_empty && open_mask != (1u << RT_SLOTS) - 1u) {
+        if (!fill_open && !queue_empty && __popc(open_mask) < slots_cap) {
           int item = 0;
           if (lane == 0) item = (int)atomicAdd(queue, 1u);
           item = __builtin_amdgcn_readfirstlane(item);
@@ -2465,7 +2458,8 @@ __global__ void __launch_bounds__(64, GENERAL < 2 ? RT_STACK_WAVES : 5) render_s
       // back to the shading phase when enough of the live lanes have a finished ray (RT_READY_LANES in 64)
       const int n_alive = __popcll(__ballot(alive));
       const int n_ready = n_alive - __popcll(__ballot(trav));
-      if (n_ready * 64 >= a_ready * n_alive) break;
+      // (the second test ends the phase when no lane is left in a traversal, whatever the threshold is)
+      if (n_ready * 64 >= a_ready * n_alive || n_ready == n_alive) break;
     }
   }
 
@@ -2556,6 +2550,7 @@ static __device__ __align__(256) unsigned char scratch[RT_NOALLOC_SCRATCH_BYTES]
 // ---------------------------------------------------------------------------
 // Host side of the ABI
 // ---------------------------------------------------------------------------
+#define RT_OPT_COUNT 9  // RT_OPT_* of rt_abi.h are 1..8
 struct rt_ctx {
   int device;
   bool has_scene;
@@ -2591,9 +2586,32 @@ struct rt_ctx {
   hipEvent_t ev_launch;      // recorded after the last enqueued render: a launch on another stream waits for it,
   hipStream_t last_stream;   // because all launches of a context share its work counter and slabs
   bool launched;
+  int opt[RT_OPT_COUNT];     // context options (rt_set_option), indexed by RT_OPT_*; defaults from the environment, read once in rt_create
+  double upload_ms[2];       // wall time of the last rt_upload_scene: host build, device copies
 };
 
 namespace {
+
+// Range and default of every context option, and the environment variable that can preset it (read once, in rt_create).
+struct OptSpec {
+  int lo, hi, def;
+  const char* env;
+};
+const OptSpec kOptSpec[RT_OPT_COUNT] = {
+    {0, 0, 0, nullptr},
+    {0, 1, 0, "RT_NO_ACCUMULATE"},        // RT_OPT_FIXED_ORDER
+    {0, 64, 0, "RT_READY_LANES"},         // RT_OPT_READY_LANES (0: per scene)
+    {1, 64, 16, "RT_HOLD_LANES"},         // RT_OPT_HOLD_LANES
+    {1, 64, RT_STACK_LDS_RENDER, "RT_STACK_LDS_CAP"},  // RT_OPT_STACK_LDS_ENTRIES
+    {1, 32, 32, "RT_WAVES_PER_CU"},       // RT_OPT_WAVES_PER_CU
+    {1, 1000, 30, "RT_WANT_ROUNDS"},      // RT_OPT_ITEM_ROUNDS
+    {0, 65536, 0, "RT_MIN_CHUNK_SPP"},    // RT_OPT_MIN_CHUNK_SPP (0: per launch)
+    {1, 65536, RT_STACK_LAST_SPP, "RT_STACK_LAST_SPP"},  // RT_OPT_LAST_CHUNK_SPP
+};
+int clamp_opt(int option, int value) {
+  const OptSpec& o = kOptSpec[option];
+  return value < o.lo ? o.lo : (value > o.hi ? o.hi : value);
+}
 
 int hip_fail(hipError_t e, const char* what) {
   return rt::set_error(RT_ERR_DEVICE, std::string(what) + ": " + hipGetErrorString(e));
@@ -3260,15 +3278,16 @@ int launch_render(rt_ctx* ctx, const rt_camera* cam, const rt_render_params* p, 
   // across an image with media; a short launch, one shard of eight, lost a quarter of its time to its last items).
   // (The order of those adds depends on scheduling, so a pixel's sum can differ in its last bits from run to run;
   // the flat and scan kernels keep their fixed order.)
-  A.accumulate = (trav == TRAV_STACK && !getenv("RT_NO_ACCUMULATE")) ? 1 : 0;  // (the variable: A/B against partial images)
-  long long want_items = 256LL * 24 * 30;
+  // RT_OPT_FIXED_ORDER gives the partial images back, and one open item per wave: bit-reproducible sums.
+  A.accumulate = (trav == TRAV_STACK && !ctx->opt[RT_OPT_FIXED_ORDER]) ? 1 : 0;
+  A.max_slots = ctx->opt[RT_OPT_FIXED_ORDER] ? 1 : 8;
+  const long long want_items = 256LL * 24 * ctx->opt[RT_OPT_ITEM_ROUNDS];
   int min_chunk_spp = A.accumulate ? 16 : 32;
-  if (const char* e = getenv("RT_WANT_ROUNDS")) want_items = 256LL * 24 * (atoi(e) > 0 ? atoi(e) : 30);  // tuning
   // a small launch of the stack kernel (fewer items than a few per wave slot the chip has) takes smaller items, down to
   // 2 samples: its time is the serial chain of paths inside one item (Book-1 scene at 400x225 @ 16: 1.33 -> 0.91 ms)
   if (A.accumulate)
     while (min_chunk_spp > 2 && (long long)n_tiles * (p->spp / min_chunk_spp) < 80LL * (ctx->n_cus > 0 ? ctx->n_cus : 1)) min_chunk_spp /= 2;
-  if (const char* e = getenv("RT_MIN_CHUNK_SPP")) min_chunk_spp = atoi(e) > 0 ? atoi(e) : min_chunk_spp;
+  if (ctx->opt[RT_OPT_MIN_CHUNK_SPP] > 0) min_chunk_spp = ctx->opt[RT_OPT_MIN_CHUNK_SPP];
   long long chunks = (want_items + n_tiles - 1) / n_tiles;
   const long long max_by_spp = p->spp / min_chunk_spp > 1 ? p->spp / min_chunk_spp : 1;
   if (chunks > max_by_spp) chunks = max_by_spp;
@@ -3285,8 +3304,7 @@ int launch_render(rt_ctx* ctx, const rt_camera* cam, const rt_render_params* p, 
   if (A.accumulate) {
     // no partial images to pay for: halve further, down to RT_STACK_LAST_SPP samples
     const int last = p->spp - (A.n_chunks - 1) * A.chunk_spp;
-    int floor_spp = RT_STACK_LAST_SPP;
-    if (const char* e = getenv("RT_STACK_LAST_SPP")) floor_spp = atoi(e) > 0 ? atoi(e) : floor_spp;  // tuning
+    const int floor_spp = ctx->opt[RT_OPT_LAST_CHUNK_SPP];
     while (A.split_parts < 8 && (last >> A.split_parts) >= floor_spp) {
       ++A.split_parts;
       ++A.n_chunks;
@@ -3300,10 +3318,8 @@ int launch_render(rt_ctx* ctx, const rt_camera* cam, const rt_render_params* p, 
     }
   }
   // scenes with media or the older materials have the heavier shading phase: it is run for fuller waves
-  A.ready_lanes = ctx->general != 0 ? 56 : RT_READY_LANES;
-  if (const char* e = getenv("RT_READY_LANES")) A.ready_lanes = atoi(e);  // tuning
-  A.hold_lanes = 16;
-  if (const char* e = getenv("RT_HOLD_LANES")) A.hold_lanes = atoi(e);
+  A.ready_lanes = ctx->opt[RT_OPT_READY_LANES] > 0 ? ctx->opt[RT_OPT_READY_LANES] : (ctx->general != 0 ? 56 : RT_READY_LANES);
+  A.hold_lanes = ctx->opt[RT_OPT_HOLD_LANES];
   float* k_sum = d_sum;
   float* k_sumsq = d_sumsq;
   unsigned* d_queue = no_alloc ? (unsigned*)ctx->scratch_ptr : ctx->d_queue;
@@ -3337,16 +3353,14 @@ int launch_render(rt_ctx* ctx, const rt_camera* cam, const rt_render_params* p, 
   const dim3 block(64);
   // One wave for every slot a CU has (8 per SIMD); where the kernel's registers allow fewer, the rest
   // start when the first waves are done, find no item left and leave.  Never more waves than items.
-  long long waves = 32LL * (ctx->n_cus > 0 ? ctx->n_cus : 1);
-  if (const char* e = getenv("RT_WAVES_PER_CU")) waves = (long long)(atoi(e) > 0 ? atoi(e) : 32) * (ctx->n_cus > 0 ? ctx->n_cus : 1);  // tuning
+  long long waves = (long long)ctx->opt[RT_OPT_WAVES_PER_CU] * (ctx->n_cus > 0 ? ctx->n_cus : 1);
   if (waves > n_items) waves = n_items;
   // The stack kernel keeps the first entries of a lane's stack in LDS (what decides how many waves a CU holds) and
   // the rest of the scene's worst case in global memory, one region per wave of the grid.
   A.stack_lds = 0;
   A.stack_ovf = nullptr;
   if (trav == TRAV_STACK) {
-    int cap = RT_STACK_LDS_RENDER;
-    if (const char* e = getenv("RT_STACK_LDS_CAP")) cap = atoi(e) > 0 ? atoi(e) : cap;  // tuning
+    const int cap = ctx->opt[RT_OPT_STACK_LDS_ENTRIES];
     A.stack_lds = ctx->dev.stack_depth < cap ? ctx->dev.stack_depth : cap;
     const size_t ovf_bytes = (size_t)waves * (size_t)(ctx->dev.stack_depth - A.stack_lds) * 128 * sizeof(unsigned);
     if (ovf_bytes > 0 && no_alloc) {
@@ -3360,7 +3374,7 @@ int launch_render(rt_ctx* ctx, const rt_camera* cam, const rt_render_params* p, 
       const size_t per_entry = (size_t)waves * 128 * sizeof(unsigned);
       const int fit = (int)((RT_NOALLOC_SCRATCH_BYTES - at) / per_entry);
       if (ctx->dev.stack_depth - A.stack_lds > fit) A.stack_lds = ctx->dev.stack_depth - fit;
-      A.stack_ovf = (unsigned*)(ctx->scratch_ptr + at);
+      A.stack_ovf = ctx->dev.stack_depth - A.stack_lds > 0 ? (unsigned*)(ctx->scratch_ptr + at) : nullptr;
     } else if (ovf_bytes > 0) {
       if (ovf_bytes > ctx->stack_ovf_bytes) {
         if (ctx->d_stack_ovf) HIP_TRY(hipFree(ctx->d_stack_ovf));
@@ -3458,6 +3472,11 @@ int rt_create(int device_id, rt_ctx** out) {
   rt_ctx* ctx = new rt_ctx();
   std::memset(ctx, 0, sizeof(*ctx));
   ctx->device = device_id;
+  for (int k = 1; k < RT_OPT_COUNT; ++k) {
+    ctx->opt[k] = kOptSpec[k].def;
+    const char* e = kOptSpec[k].env ? getenv(kOptSpec[k].env) : nullptr;
+    if (e && *e) ctx->opt[k] = clamp_opt(k, k == RT_OPT_FIXED_ORDER ? 1 : atoi(e));
+  }
   hipDeviceProp_t prop;
   e = hipGetDeviceProperties(&prop, device_id);
   ctx->n_cus = e == hipSuccess ? prop.multiProcessorCount : 0;
@@ -3475,6 +3494,20 @@ int rt_create(int device_id, rt_ctx** out) {
     return hip_fail(e, "rt_create");
   }
   *out = ctx;
+  return RT_OK;
+}
+
+int rt_set_option(rt_ctx* ctx, int option, int value) {
+  if (!ctx) return rt::set_error(RT_ERR_INVALID, "rt_set_option: null context");
+  if (option < 1 || option >= RT_OPT_COUNT) return rt::set_error(RT_ERR_INVALID, "rt_set_option: unknown option");
+  ctx->opt[option] = clamp_opt(option, value);
+  return RT_OK;
+}
+
+int rt_get_option(const rt_ctx* ctx, int option, int* value_out) {
+  if (!ctx || !value_out) return rt::set_error(RT_ERR_INVALID, "rt_get_option: null argument");
+  if (option < 1 || option >= RT_OPT_COUNT) return rt::set_error(RT_ERR_INVALID, "rt_get_option: unknown option");
+  *value_out = ctx->opt[option];
   return RT_OK;
 }
 
@@ -3505,8 +3538,11 @@ int rt_destroy(rt_ctx* ctx) {
   return RT_OK;
 }
 
-int rt_upload_scene(rt_ctx* ctx, const rt_scene* s) {
+int rt_upload_scene(rt_ctx* ctx, const rt_scene* s) { return rt_upload_scene_timed(ctx, s, nullptr); }
+
+int rt_upload_scene_timed(rt_ctx* ctx, const rt_scene* s, double* upload_ms) {
   if (!ctx) return rt::set_error(RT_ERR_INVALID, "rt_upload_scene: null context");
+  const auto t_begin = std::chrono::steady_clock::now();
   int rc = validate_scene(s);
   if (rc != RT_OK) return rc;
   ScanBuilder B;
@@ -3590,6 +3626,7 @@ int rt_upload_scene(rt_ctx* ctx, const rt_scene* s) {
     }
   }
   const std::vector<ScanNode>& scan = stack_mode ? media_scan : B.out;
+  const auto t_built = std::chrono::steady_clock::now();
   HIP_TRY(hipSetDevice(ctx->device));
   free_scene(ctx);
   if ((rc = upload(&ctx->d_scan, scan.data(), scan.size())) != RT_OK) return rc;
@@ -3690,6 +3727,10 @@ int rt_upload_scene(rt_ctx* ctx, const rt_scene* s) {
   // (the general light code is compiled into build 3 only, so that the other builds keep their registers)
   ctx->general = d.light_general ? 3 : textured ? 2 : ((!B.media.empty() || (mat_mask & ~((1 << RT_MAT_LAMBERTIAN) | (1 << RT_MAT_DIFFUSE_LIGHT))) != 0) ? 1 : 0);
   ctx->has_scene = true;
+  const auto t_end = std::chrono::steady_clock::now();
+  ctx->upload_ms[0] = std::chrono::duration<double, std::milli>(t_built - t_begin).count();
+  ctx->upload_ms[1] = std::chrono::duration<double, std::milli>(t_end - t_built).count();
+  if (upload_ms) { upload_ms[0] = ctx->upload_ms[0]; upload_ms[1] = ctx->upload_ms[1]; }
   return RT_OK;
 }
 

@@ -16,8 +16,8 @@
 // rank from ncclCommInitAll, each on its rank's stream) when all device ids are
 // distinct; with repeated ids (or RT_MULTI_NO_RCCL) the frames are copied to rank
 // 0's device and added or unpacked there in rank order.  librccl.so is opened with
-// dlopen when the first multi-context that needs it is created: single-GPU users of
-// the library never load it.
+// dlopen when the first multi-context of more than one distinct device is created:
+// single-GPU users of the library never load it.
 #include <hip/hip_runtime.h>
 
 #include <dlfcn.h>
@@ -56,6 +56,12 @@ struct Rccl {
 const int kNcclFloat = 7;  // ncclFloat32 in rccl.h's ncclDataType_t
 const int kNcclSum = 0;    // ncclSum in ncclRedOp_t
 
+// Why the library could not be used, kept from the failing dlopen/dlsym itself: dlerror() hands its message out once
+// and any later library call may replace it.
+std::string& rccl_load_error() {
+  static std::string text;
+  return text;
+}
 Rccl* load_rccl() {
   static Rccl r;
   static bool tried = false, ok = false;
@@ -63,10 +69,18 @@ Rccl* load_rccl() {
   tried = true;
   r.handle = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
   if (!r.handle) r.handle = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
-  if (!r.handle) return nullptr;
+  if (!r.handle) {
+    const char* why = dlerror();
+    rccl_load_error() = why ? why : "dlopen failed";
+    return nullptr;
+  }
 #define RT_SYM(field, name)                                        \
   *(void**)(&r.field) = dlsym(r.handle, name);                     \
-  if (!r.field) return nullptr;
+  if (!r.field) {                                                  \
+    const char* why = dlerror();                                   \
+    rccl_load_error() = why ? why : "missing symbol " name;        \
+    return nullptr;                                                \
+  }
   RT_SYM(CommInitAll, "ncclCommInitAll")
   RT_SYM(CommDestroy, "ncclCommDestroy")
   RT_SYM(GroupStart, "ncclGroupStart")
@@ -129,6 +143,7 @@ struct rt_multi {
   bool use_rccl;
   Rccl* rccl;
   std::vector<comm_t> comm;
+  std::string rccl_note;  // why RCCL is not in use although it was wanted
 };
 
 namespace {
@@ -164,7 +179,9 @@ int exchange(rt_multi* m, const rt_render_params* p, int shard_mode, std::vector
              std::vector<size_t>& packed_floats) {
   const size_t n = (size_t)p->nx * p->ny * 3;
   const int N = m->n;
-  if (N == 1) return RT_OK;
+  // One rank has nothing to exchange.  With RT_MULTI_FORCE_RCCL it still goes through the calls (a reduce onto itself, an
+  // empty send/receive group), so that the resolved entry points, their signatures and the enum values run on one GPU.
+  if (N == 1 && !m->use_rccl) return RT_OK;
   const size_t block_floats = 8 * 8 * 3;
   if (shard_mode == RT_SHARD_TILES) {
     // every other rank packs its blocks
@@ -273,7 +290,7 @@ int rt_multi_destroy(rt_multi* m) {
 
 int rt_multi_create(const int* device_ids, int n_devices, unsigned flags, rt_multi** out) {
   if (!out || !device_ids || n_devices < 1 || n_devices > 64) return rt::set_error(RT_ERR_INVALID, "rt_multi_create: bad argument");
-  if (flags & ~(unsigned)RT_MULTI_NO_RCCL) return rt::set_error(RT_ERR_INVALID, "rt_multi_create: unknown flag");
+  if (flags & ~(unsigned)(RT_MULTI_NO_RCCL | RT_MULTI_FORCE_RCCL)) return rt::set_error(RT_ERR_INVALID, "rt_multi_create: unknown flag");
   rt_multi* m = new rt_multi();
   const size_t N = (size_t)n_devices;
   m->n = n_devices;
@@ -304,22 +321,34 @@ int rt_multi_create(const int* device_ids, int n_devices, unsigned flags, rt_mul
   for (int a = 0; a < n_devices; ++a)
     for (int b = a + 1; b < n_devices; ++b)
       if (device_ids[a] == device_ids[b]) distinct = false;
-  if (distinct && !(flags & RT_MULTI_NO_RCCL)) {
+  // RCCL only where there is something to exchange between distinct devices (a one-rank context never loads it, unless
+  // RT_MULTI_FORCE_RCCL asks for the calls to be exercised).  When the library cannot be loaded or initialised the
+  // context falls back to the exchange by device copies (which every test covers) and rt_multi_uses_rccl() says so;
+  // with RT_MULTI_FORCE_RCCL that is an error instead.
+  const bool force = (flags & RT_MULTI_FORCE_RCCL) != 0;
+  if (distinct && !(flags & RT_MULTI_NO_RCCL) && (n_devices > 1 || force)) {
+    std::string why;
     m->rccl = load_rccl();
     if (!m->rccl) {
-      rt_multi_destroy(m);
-      return rt::set_error(RT_ERR_DEVICE, std::string("rt_multi_create: cannot load librccl.so (") + (dlerror() ? dlerror() : "missing symbol") +
-                                            "); pass RT_MULTI_NO_RCCL to exchange by device copies instead");
+      why = "cannot load librccl.so (" + rccl_load_error() + ")";
+    } else {
+      m->comm.assign(N, nullptr);
+      const int c = m->rccl->CommInitAll(m->comm.data(), n_devices, device_ids);
+      if (c != 0) {
+        why = std::string("ncclCommInitAll: ") + (m->rccl->GetErrorString ? m->rccl->GetErrorString(c) : "RCCL error");
+        m->comm.clear();
+      } else {
+        m->use_rccl = true;
+      }
     }
-    m->comm.assign(N, nullptr);
-    const int c = m->rccl->CommInitAll(m->comm.data(), n_devices, device_ids);
-    if (c != 0) {
-      const int rc = nccl_fail(m->rccl, c, "ncclCommInitAll");
-      m->comm.clear();
-      rt_multi_destroy(m);
-      return rc;
+    if (!m->use_rccl) {
+      m->rccl_note = why;
+      if (force) {
+        rt_multi_destroy(m);
+        return rt::set_error(RT_ERR_DEVICE, "rt_multi_create: " + why);
+      }
+      std::fprintf(stderr, "rt_multi_create: %s; exchanging by device copies instead\n", why.c_str());
     }
-    m->use_rccl = true;
   }
   *out = m;
   return RT_OK;

@@ -30,7 +30,21 @@ class Renderer(object):
             pass
 
     def upload_scene(self, flat_scene):
-        check(_lib.lib().rt_upload_scene(self._ctx, C.byref(flat_scene)))
+        """rt_upload_scene; the wall time of its two parts (host build of the
+        device's tree views, device copies) is kept in `upload_ms`."""
+        ms = (C.c_double * 2)()
+        check(_lib.lib().rt_upload_scene_timed(self._ctx, C.byref(flat_scene), ms))
+        self.upload_ms = (float(ms[0]), float(ms[1]))
+
+    def set_option(self, option, value):
+        """rt_set_option: a context option (RT_OPT_* of rt_abi.h); out-of-range
+        values are clamped by the library."""
+        check(_lib.lib().rt_set_option(self._ctx, int(option), int(value)))
+
+    def get_option(self, option):
+        v = C.c_int(0)
+        check(_lib.lib().rt_get_option(self._ctx, int(option), C.byref(v)))
+        return int(v.value)
 
     def render(self, camera, params, want_sumsq=False, want_stats=False):
         """Blocking render to host arrays: per-pixel sums, shape (ny, nx, 3),
@@ -149,11 +163,12 @@ class MultiRenderer(object):
     fan-out and the image sum of main.rs:70-133 with GPUs for threads.  A device id
     may repeat (ranks that share a GPU)."""
 
-    def __init__(self, device_ids, no_rccl=False):
+    def __init__(self, device_ids, no_rccl=False, force_rccl=False):
         ids = (C.c_int * len(device_ids))(*device_ids)
         self._m = C.c_void_p()
         self.n = len(device_ids)
-        check(_lib.lib().rt_multi_create(ids, len(device_ids), _lib.RT_MULTI_NO_RCCL if no_rccl else 0, C.byref(self._m)))
+        flags = (_lib.RT_MULTI_NO_RCCL if no_rccl else 0) | (_lib.RT_MULTI_FORCE_RCCL if force_rccl else 0)
+        check(_lib.lib().rt_multi_create(ids, len(device_ids), flags, C.byref(self._m)))
 
     @property
     def uses_rccl(self):

@@ -11,6 +11,20 @@ if ROOT not in sys.path:
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
+def log_achieved(name, **values):
+    """Appends what a parity test measured (fractions of equal pixels, z statistics)
+    to gpurun_out/parity_achieved.jsonl, so that the bars in the tests can be set from
+    what the kernels achieve.  Does nothing where that directory does not exist."""
+    import inspect
+    import json
+    out = os.path.join(ROOT, "gpurun_out")
+    if not os.path.isdir(out):
+        return
+    caller = next((f.function for f in inspect.stack()[1:] if f.function.startswith("test_")), "?")
+    with open(os.path.join(out, "parity_achieved.jsonl"), "a") as fh:
+        fh.write(json.dumps(dict(test=caller, what=name, **{k: float(v) for k, v in values.items()})) + "\n")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

@@ -11,6 +11,8 @@ from raytracing_amd import Scene, make_params
 from raytracing_amd import scenes
 from raytracing_amd.distributed import shard_tile_mask
 
+from conftest import log_achieved
+
 pytestmark = pytest.mark.gpu
 
 
@@ -122,8 +124,11 @@ def test_million_sphere_render_at_3840x2160(gpu, orc, stress_scene):
     blocks = shard_tile_mask(nx, ny, 7, 40)
     assert not part[~blocks].any() and not o[~blocks].any()
     a, b = part[blocks], o[blocks]
-    assert np.isclose(a, b, rtol=5e-3, atol=5e-3).mean() > 0.9, np.isclose(a, b, rtol=5e-3, atol=5e-3).mean()
-    assert abs(a.sum() - b.sum()) / b.sum() < 0.03, (a.sum(), b.sum())
+    log_achieved("same_seed", close=np.isclose(a, b, rtol=5e-3, atol=5e-3).mean(), tight=np.isclose(a, b, rtol=2e-4, atol=1e-4).mean(),
+                 energy=abs(a.sum() - b.sum()) / b.sum())
+    assert np.isclose(a, b, rtol=5e-3, atol=5e-3).mean() > 0.995, np.isclose(a, b, rtol=5e-3, atol=5e-3).mean()  # achieved: 0.9988
+    assert np.isclose(a, b, rtol=2e-4, atol=1e-4).mean() > 0.99  # achieved: 0.9963
+    assert abs(a.sum() - b.sum()) / b.sum() < 0.005, (a.sum(), b.sum())
 
 
 def test_final_scene_at_1920x1080(gpu, orc):
@@ -140,12 +145,14 @@ def test_final_scene_at_1920x1080(gpu, orc):
     assert st.paths == nx * ny
     o, ost = orc.render(flat, cam.c, p, mode=orc.ORC_F32_FUSED, n_threads=16, want_sumsq=False, want_stats=True)
     close = np.isclose(s, o, rtol=5e-3, atol=5e-3)
-    assert close.mean() > 0.9, close.mean()
-    assert abs(s.sum() - o.sum()) / o.sum() < 0.02, (s.sum(), o.sum())
+    log_achieved("same_seed", close=close.mean(), tight=np.isclose(s, o, rtol=2e-4, atol=1e-4).mean(), energy=abs(s.sum() - o.sum()) / o.sum(),
+                 corner0=close[0:64, 0:64].mean(), corner1=close[ny - 64:ny, nx - 64:nx].mean(), centre=close[500:600, 900:1000].mean())
+    assert close.mean() > 0.998, close.mean()  # achieved: 0.99991 (0.99938 of the sums to 2e-4)
+    assert abs(s.sum() - o.sum()) / o.sum() < 0.002, (s.sum(), o.sum())
     # the device ends a path whose weight has become exactly zero (its sample is zero whatever follows); the oracle walks on
     assert 0.8 * ost.rays < st.rays <= ost.rays, (st.rays, ost.rays)
     for ys, xs in ((slice(0, 64), slice(0, 64)), (slice(ny - 64, ny), slice(nx - 64, nx)), (slice(500, 600), slice(900, 1000))):
-        assert close[ys, xs].mean() > 0.85
+        assert close[ys, xs].mean() > 0.99  # achieved: 1, 1, 0.999
     second = gpu.render(cam, make_params(nx, ny, 1, seed=21, sample_begin=1))
     both = gpu.render(cam, make_params(nx, ny, 2, seed=21))
     assert np.allclose(both, s + second, rtol=1e-6, atol=1e-6)
@@ -166,10 +173,12 @@ def test_cornell_glass_and_smoke_at_7680x4320(gpu, orc):
     assert st.paths == nx * ny
     o = orc.render(flat, cam.c, p, mode=orc.ORC_F32_FUSED, n_threads=16, want_sumsq=False)
     close = np.isclose(s, o, rtol=5e-3, atol=5e-3)
-    assert close.mean() > 0.95, close.mean()
-    assert abs(float(s.sum(dtype=np.float64)) - o.sum()) / o.sum() < 0.01
+    log_achieved("same_seed", close=close.mean(), tight=np.isclose(s, o, rtol=2e-4, atol=1e-4).mean(),
+                 corner0=close[0:64, 0:64].mean(), corner1=close[ny - 64:ny, nx - 64:nx].mean(), centre=close[2100:2200, 3800:3900].mean())
+    assert close.mean() > 0.9995, close.mean()  # achieved: 0.99999
+    assert abs(float(s.sum(dtype=np.float64)) - o.sum()) / o.sum() < 0.001
     for ys, xs in ((slice(0, 64), slice(0, 64)), (slice(ny - 64, ny), slice(nx - 64, nx)), (slice(2100, 2200), slice(3800, 3900))):
-        assert close[ys, xs].mean() > 0.9
+        assert close[ys, xs].mean() > 0.995  # achieved: 1, 1, 1
     del o, close
     total = np.zeros_like(s)
     owner = np.zeros((ny, nx), dtype=np.int32)

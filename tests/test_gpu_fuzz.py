@@ -96,4 +96,4 @@ def test_random_scenes_render_tracks_oracle(gpu, orc, seed, n_items, media):
         sc.light_xz_rect(-4.0, 4.0, -4.0, 4.0, 14.0)
         cam = S.Camera.new(S.vec3(0.0, 6.0, -34.0), S.vec3(0.0, 0.0, 0.0), S.vec3(0.0, 1.0, 0.0), 40.0, 1.5, 0.0, 10.0)
         flat = sc.flatten(S.HitableList.new(items))
-        _compare(gpu, orc, flat, cam, 48, 32, 48, sky=_lib.RT_SKY_GRADIENT, same_frac=0.75, energy_tol=0.03)
+        _compare(gpu, orc, flat, cam, 48, 32, 48, sky=_lib.RT_SKY_GRADIENT, same_frac=0.985, tight_frac=0.95, energy_tol=0.005)

@@ -10,27 +10,36 @@ import pytest
 from raytracing_amd import Scene, _lib, make_params
 from raytracing_amd import scene as S
 from raytracing_amd import scenes
+from conftest import log_achieved
 from test_gpu_render import _z_scores
 
 pytestmark = pytest.mark.gpu
 
 
-def _compare(gpu, orc, flat, camera, nx, ny, spp, sky=_lib.RT_SKY_BLACK, max_depth=50, same_frac=0.9, energy_tol=0.02):
-    """Same seed against the fp32 oracle (most pixel sums equal to rounding), then
-    independent seeds against the f64 oracle (3-standard-error test)."""
+def _compare(gpu, orc, flat, camera, nx, ny, spp, sky=_lib.RT_SKY_BLACK, max_depth=50, same_frac=0.985, tight_frac=0.95, energy_tol=0.005):
+    """Same seed against the fp32 oracle, then independent seeds against the f64 oracle (3-standard-error test).
+    Same seed: the device draws the oracle's random numbers, so a pixel sum differs only where a last-bit difference
+    in shading sent a path to another surface: at least `same_frac` of the sums agree to 0.5 %, at least `tight_frac`
+    to fp32 accuracy (2e-4), and the image's energy to `energy_tol`.  The bars are what the kernels achieve on these
+    scenes (0.997 or more of the sums to 0.5 %, 0.977 or more to 2e-4, energy to 2e-4) less a margin; the room ten times
+    the Cornell box, where fp32 coordinates are coarser, gets 0.988 / 0.911 and has bars of its own."""
     gpu.upload_scene(flat)
     p = make_params(nx, ny, spp, seed=77, sky=sky, max_depth=max_depth)
     s, s2 = gpu.render(camera, p, want_sumsq=True)
     o, o2 = orc.render(flat, camera.c, p, mode=orc.ORC_F32_FUSED)
     assert np.isfinite(s).all()
     close = np.isclose(s, o, rtol=5e-3, atol=5e-3 * spp).mean()
+    tight = np.isclose(s, o, rtol=2e-4, atol=1e-4 * spp).mean()
+    log_achieved("same_seed", close=close, tight=tight, energy=abs(s.sum() - o.sum()) / o.sum(), bar=same_frac)
     assert close > same_frac, close
+    assert tight > tight_frac, tight
     assert abs(s.sum() - o.sum()) / o.sum() < energy_tol, (s.sum(), o.sum())
     q = make_params(nx, ny, spp, seed=78, sky=sky, max_depth=max_depth)
     r, r2 = orc.render(flat, camera.c, q, mode=orc.ORC_F64)
     ma, mb, se, z = _z_scores(s.astype(np.float64), s2.astype(np.float64), r, r2, spp)
     valid = se > 0
     zz = z[valid]
+    log_achieved("z_test", frac_over_3=(np.abs(zz) > 3).mean(), mean_z=zz.mean())
     assert (np.abs(zz) > 3).mean() < 0.02, (np.abs(zz) > 3).mean()
     assert abs(zz.mean()) < 0.08, zz.mean()
     # image means agree within 4 standard errors of their difference (or 3 %)
@@ -52,7 +61,7 @@ def test_metal_dielectric_lens_and_sky_gradient(gpu, orc):
         ]
         cam = S.Camera.new(S.vec3(13.0, 2.0, 3.0), S.vec3(0.0, 0.0, 0.0), S.vec3(0.0, 1.0, 0.0), 20.0, 1.5, 0.1, 10.0)
         flat = sc.flatten(S.HitableList.new(items))
-        _compare(gpu, orc, flat, cam, 60, 40, 64, sky=_lib.RT_SKY_GRADIENT, same_frac=0.8)
+        _compare(gpu, orc, flat, cam, 60, 40, 64, sky=_lib.RT_SKY_GRADIENT)
 
 
 def test_checker_and_noise_textures(gpu, orc):
@@ -70,7 +79,7 @@ def test_checker_and_noise_textures(gpu, orc):
         cam = S.Camera.new(S.vec3(30.0, 2.0, 3.0), S.vec3(0.0, 0.0, 0.0), S.vec3(0.0, 1.0, 0.0), 20.0, 1.5, 0.0, 10.0)
         flat = sc.flatten(S.HitableList.new(items))
         assert flat.n_perlins == 1
-        _compare(gpu, orc, flat, cam, 60, 40, 64, sky=_lib.RT_SKY_GRADIENT, same_frac=0.85)
+        _compare(gpu, orc, flat, cam, 60, 40, 64, sky=_lib.RT_SKY_GRADIENT)
 
 
 def test_cornell_smoke_with_glass_and_mirror(gpu, orc):
@@ -81,7 +90,7 @@ def test_cornell_smoke_with_glass_and_mirror(gpu, orc):
         sc.light_xz_rect(*scenes.SMOKE_LIGHT_SHAPE)
         flat = sc.flatten(world)
         assert flat.n_objects == 1 and flat.objects[0].kind == _lib.RT_OBJ_MEDIUM
-        _compare(gpu, orc, flat, cam, 48, 48, 64, same_frac=0.8, energy_tol=0.03)
+        _compare(gpu, orc, flat, cam, 48, 48, 64)
 
 
 def test_medium_in_rotated_box(gpu, orc):
@@ -95,7 +104,7 @@ def test_medium_in_rotated_box(gpu, orc):
         items = world0.list[:6] + [S.ConstantMedium.new(box, 0.01, S.Texture.new_constant(S.scalar(0.9)))]
         sc.light_xz_rect(*scenes.MAIN_RS_LIGHT_SHAPE)
         flat = sc.flatten(S.HitableList.new(items))
-        _compare(gpu, orc, flat, cam, 48, 48, 64, same_frac=0.8)
+        _compare(gpu, orc, flat, cam, 48, 48, 64)
 
 
 def test_trace_skips_media_and_sees_general_scenes(gpu, orc):
@@ -144,7 +153,7 @@ def test_large_tree_render_lambertian(gpu, orc):
         sc.light_xz_rect(-3.0, 3.0, -3.0, 3.0, 6.0)
         flat = sc.flatten(world)
         assert flat.n_nodes > 64
-        _compare(gpu, orc, flat, cam, 60, 40, 64, same_frac=0.9)
+        _compare(gpu, orc, flat, cam, 60, 40, 64)
 
 
 def test_large_tree_render_all_materials(gpu, orc):
@@ -153,7 +162,7 @@ def test_large_tree_render_all_materials(gpu, orc):
     with Scene(22) as sc:
         cam, world = _sphere_field(150, 6, glass_and_metal=True)
         flat = sc.flatten(world)
-        _compare(gpu, orc, flat, cam, 60, 40, 64, sky=_lib.RT_SKY_GRADIENT, same_frac=0.8)
+        _compare(gpu, orc, flat, cam, 60, 40, 64, sky=_lib.RT_SKY_GRADIENT)
 
 
 def test_long_primitive_list_render(gpu, orc):
@@ -172,7 +181,7 @@ def test_long_primitive_list_render(gpu, orc):
         sc.light_xz_rect(*scenes.MAIN_RS_LIGHT_SHAPE)
         flat = sc.flatten(S.HitableList.new(world0.list[:6] + [blinds]))
         assert flat.n_prims > 64
-        _compare(gpu, orc, flat, cam, 48, 48, 64, same_frac=0.9)
+        _compare(gpu, orc, flat, cam, 48, 48, 64)
 
 
 @pytest.mark.parametrize("name", ["random", "final", "stress"])
@@ -193,7 +202,7 @@ def test_named_scene_builders_render_like_the_oracle(gpu, orc, name):
             sc.light_xz_rect(*scenes.STRESS_LIGHT_SHAPE)
         flat = sc.flatten(world)
         assert flat.n_nodes > 64
-        _compare(gpu, orc, flat, cam, 60, 40, 64, same_frac=0.75, energy_tol=0.05)
+        _compare(gpu, orc, flat, cam, 60, 40, 64)
 
 
 def test_room_ten_times_the_cornell_box(gpu, orc):
@@ -213,7 +222,7 @@ def test_room_ten_times_the_cornell_box(gpu, orc):
     op, ot = orc.trace_closest(flat, o, d, mode=orc.ORC_F32_FUSED)
     assert np.array_equal(prim, op) and np.array_equal(t, ot.astype(np.float32))
     assert (prim >= 0).mean() > 0.85
-    _compare(gpu, orc, flat, cam, 48, 48, 128, same_frac=0.9)
+    _compare(gpu, orc, flat, cam, 48, 48, 128, same_frac=0.975, tight_frac=0.88)
 
 
 def test_medium_in_a_box_of_the_ten_times_room(gpu, orc):
@@ -233,7 +242,7 @@ def test_medium_in_a_box_of_the_ten_times_room(gpu, orc):
     _, st32 = orc.render(flat, cam.c, p, mode=orc.ORC_F32_FUSED, want_sumsq=False, want_stats=True)
     _, st64 = orc.render(flat, cam.c, p, mode=orc.ORC_F64, want_sumsq=False, want_stats=True)
     assert abs(st32.hits - st64.hits) < 0.003 * st64.hits, (st32.hits, st64.hits)
-    _compare(gpu, orc, flat, cam, 48, 48, 64, same_frac=0.8)
+    _compare(gpu, orc, flat, cam, 48, 48, 64, same_frac=0.975, tight_frac=0.88)
 
 
 def test_long_lists_as_leaves_of_a_large_tree(gpu, orc):
@@ -259,7 +268,7 @@ def test_long_lists_as_leaves_of_a_large_tree(gpu, orc):
         sc.light_xz_rect(-3.0, 3.0, -3.0, 3.0, 6.0)
         flat = sc.flatten(S.HitableList.new(items))
         assert flat.n_prims > 700
-        _compare(gpu, orc, flat, cam, 60, 40, 64, same_frac=0.85)
+        _compare(gpu, orc, flat, cam, 60, 40, 64)
         # and the nearest hits of rays aimed down at the slats, bit for bit
         n = 6000
         o = np.stack([rng.uniform(-2.5, 2.5, n), np.full(n, 5.5), rng.uniform(-2.5, 2.5, n)], axis=1).astype(np.float32)

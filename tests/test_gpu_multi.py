@@ -1,9 +1,11 @@
 """rt_multi_*: one render over several ranks from one process (the thread fan-out
 and image sum of main.rs:70-133 with GPUs for threads).  The GPU box has one GPU,
 so ranks share it ("virtual ranks": repeated device ids, exchange by device
-copies in rank order); the RCCL exchange is driven with the one real device,
-where ncclReduce and the grouped send/recv degenerate to a single rank but the
-communicator set-up and the calls are the ones N devices take."""
+copies in rank order).  What RCCL can do on one device is driven with
+RT_MULTI_FORCE_RCCL: dlopen, ncclCommInitAll, one in-place ncclReduce of the frame
+onto the only rank and one empty send/receive group, i.e. the resolved symbols,
+their signatures and the enum values; the exchange BETWEEN devices (several ranks
+in a reduce, matched sends and receives, the staging offsets) has never run."""
 import os
 import subprocess
 
@@ -16,11 +18,28 @@ from raytracing_amd._lib import RT_ERR_INVALID
 pytestmark = pytest.mark.gpu
 
 
+def test_one_rank_needs_no_rccl(gpu, cornell):
+    m = MultiRenderer([0])
+    try:
+        assert not m.uses_rccl
+        m.upload_scene(cornell.flat)
+        p = make_params(64, 48, 8, seed=3)
+        assert np.array_equal(m.render(cornell.camera, p), gpu_render(gpu, cornell, p))
+    finally:
+        m.close()
+
+
+def gpu_render(gpu, cornell, p):
+    gpu.upload_scene(cornell.flat)
+    return gpu.render(cornell.camera, p)
+
+
 def test_one_rank_through_rccl_equals_rt_render(gpu, cornell):
+    """The RCCL calls on one rank: a reduce onto itself must leave the frame as it is."""
     gpu.upload_scene(cornell.flat)
     p = make_params(96, 80, 40, seed=3)
     want, want2 = gpu.render(cornell.camera, p, want_sumsq=True)
-    m = MultiRenderer([0])
+    m = MultiRenderer([0], force_rccl=True)
     try:
         assert m.uses_rccl
         m.upload_scene(cornell.flat)

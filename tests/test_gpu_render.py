@@ -376,3 +376,37 @@ def test_render_against_the_stored_images(gpu, cornell):
             assert (np.abs(zz) > 3.5).mean() < 0.02, (np.abs(zz) > 3.5).mean()
             assert abs(zz.mean()) < 0.15, zz.mean()
             assert abs(ma.mean() - mb.mean()) / mb.mean() < 0.08, (ma.mean(), mb.mean())
+
+
+def test_the_bench_launch_itself(gpu, orc):
+    """Exactly the launch bench.py times (cornell_box_scene at 1024x1024, 1000 samples per pixel, seed 0x5EED0001, depth
+    50): every path is traced once, the image is the same on a second launch, and the means of its 32x32-pixel blocks
+    agree with the f64 oracle's (the reference's arithmetic) at 16 samples per pixel and another seed within 3 standard
+    errors of the oracle's block means (the device's own error, at 1000 x 1024 samples per block, is a tenth of that)."""
+    from conftest import CornellFixture
+    c = CornellFixture(seed=0x5EED0001, ratio=1.0)
+    gpu.upload_scene(c.flat)
+    nx = ny = 1024
+    p = make_params(nx, ny, 1000, seed=0x5EED0001)
+    s, s2, st = gpu.render(c.camera, p, want_sumsq=True, want_stats=True)
+    assert st.paths == nx * ny * 1000
+    assert 2.3 * st.paths < st.rays < 2.7 * st.paths  # 2.489 rays per path
+    assert np.isfinite(s).all() and (s >= 0).all()
+    again = gpu.render(c.camera, p)
+    assert np.array_equal(s, again)
+    o_spp = 16
+    o, o2 = orc.render(c.flat, c.camera.c, make_params(nx, ny, o_spp, seed=0xABCD), mode=orc.ORC_F64, n_threads=16)
+    blk = lambda a: a.reshape(32, 32, 32, 32, 3).sum(axis=(1, 3))  # noqa: E731
+    n_dev, n_orc = 1000.0 * 1024, float(o_spp) * 1024
+    md, mo = blk(s.astype(np.float64)) / n_dev, blk(o) / n_orc
+    vd = np.maximum(blk(s2.astype(np.float64)) / n_dev - md * md, 0.0)
+    vo = np.maximum(blk(o2) / n_orc - mo * mo, 0.0)
+    se = np.sqrt(vd / n_dev + vo / n_orc)
+    valid = se > 0
+    z = (md - mo)[valid] / se[valid]
+    from conftest import log_achieved
+    log_achieved("bench_launch_blocks", frac_over_3=(np.abs(z) > 3).mean(), mean_z=z.mean(), std_z=z.std(), blocks=valid.sum())
+    assert valid.mean() > 0.8
+    assert (np.abs(z) > 3).mean() < 0.02, (np.abs(z) > 3).mean()
+    assert abs(z.mean()) < 0.15, z.mean()
+    assert abs(md.mean() - mo.mean()) / mo.mean() < 0.005

@@ -2,26 +2,25 @@
 in a region of global memory: with the LDS part cut to one or two entries nearly
 every push and pop goes through that region, and the image must not change (the
 stack kernel's sums agree to the order of its float adds)."""
-import os
-
 import numpy as np
 import pytest
 
 from raytracing_amd import Scene, make_params
 from raytracing_amd import scenes
+from raytracing_amd._lib import (RT_OPT_FIXED_ORDER, RT_OPT_HOLD_LANES, RT_OPT_READY_LANES, RT_OPT_STACK_LDS_ENTRIES,
+                                 RT_OPT_WAVES_PER_CU)
 
 pytestmark = pytest.mark.gpu
 
 
 @pytest.fixture
-def lds_cap():
+def lds_cap(gpu):
+    default = gpu.get_option(RT_OPT_STACK_LDS_ENTRIES)
+
     def set_cap(n):
-        if n is None:
-            os.environ.pop("RT_STACK_LDS_CAP", None)
-        else:
-            os.environ["RT_STACK_LDS_CAP"] = str(n)  # read by the library at every launch
+        gpu.set_option(RT_OPT_STACK_LDS_ENTRIES, default if n is None else n)
     yield set_cap
-    os.environ.pop("RT_STACK_LDS_CAP", None)
+    gpu.set_option(RT_OPT_STACK_LDS_ENTRIES, default)
 
 
 def test_image_does_not_depend_on_where_the_stack_lives(gpu, orc, lds_cap):
@@ -61,3 +60,58 @@ def test_final_scene_with_the_stack_in_global_memory(gpu, lds_cap):
     lds_cap(1)
     s = gpu.render(cam, p)
     assert np.allclose(s, ref, rtol=1e-5, atol=1e-4)
+
+
+def _field_150():
+    from test_gpu_materials import _sphere_field
+    with Scene(77) as sc:
+        cam, world = _sphere_field(150, 5, glass_and_metal=True)
+        sc.light_xz_rect(-3.0, 3.0, -3.0, 3.0, 6.0)
+        return cam, sc.flatten(world)
+
+
+def test_fixed_order_option_gives_equal_bits(gpu):
+    """RT_OPT_FIXED_ORDER: the stack kernel writes one partial image per work item,
+    keeps one item open per wave and adds the partial images in a fixed order, so two
+    renders of the same input agree bit for bit; without it the items meet in the
+    output through float atomics and only the tolerance holds."""
+    cam, flat = _field_150()
+    gpu.upload_scene(flat)
+    p = make_params(160, 96, 128, seed=5)
+    free = gpu.render(cam, p)
+    gpu.set_option(RT_OPT_FIXED_ORDER, 1)
+    try:
+        assert gpu.get_option(RT_OPT_FIXED_ORDER) == 1
+        a, a2, st = gpu.render(cam, p, want_sumsq=True, want_stats=True)
+        b, b2 = gpu.render(cam, p, want_sumsq=True)
+        c = gpu.render(cam, p)
+        assert st.node_tests > 4 * st.rays  # the stack traversal, not the scan
+        assert np.array_equal(a, b) and np.array_equal(a2, b2) and np.array_equal(a, c)
+    finally:
+        gpu.set_option(RT_OPT_FIXED_ORDER, 0)
+    assert np.allclose(free, a, rtol=1e-5, atol=1e-4)
+
+
+def test_tuning_options_are_clamped_and_cannot_hang_the_kernel(gpu):
+    """A threshold of more than 64 lanes in 64 could never be met: the traversal phase
+    would never hand the wave back to the shading code.  The options clamp to their
+    ranges, and the phase also ends when no lane is left in a traversal."""
+    cam, flat = _field_150()
+    gpu.upload_scene(flat)
+    p = make_params(64, 48, 16, seed=6)
+    ref = gpu.render(cam, p)
+    saved = {k: gpu.get_option(k) for k in (RT_OPT_READY_LANES, RT_OPT_HOLD_LANES, RT_OPT_STACK_LDS_ENTRIES, RT_OPT_WAVES_PER_CU)}
+    try:
+        for k, v, want in ((RT_OPT_READY_LANES, 65, 64), (RT_OPT_READY_LANES, 1 << 30, 64), (RT_OPT_HOLD_LANES, 0, 1),
+                           (RT_OPT_HOLD_LANES, 999, 64), (RT_OPT_STACK_LDS_ENTRIES, -5, 1), (RT_OPT_STACK_LDS_ENTRIES, 1000, 64),
+                           (RT_OPT_WAVES_PER_CU, 0, 1), (RT_OPT_WAVES_PER_CU, 64, 32)):
+            gpu.set_option(k, v)
+            assert gpu.get_option(k) == want
+            s = gpu.render(cam, p)
+            assert np.allclose(s, ref, rtol=1e-5, atol=1e-4), (k, v)
+            gpu.set_option(k, saved[k])
+    finally:
+        for k, v in saved.items():
+            gpu.set_option(k, v)
+    with pytest.raises(Exception):
+        gpu.set_option(99, 1)
