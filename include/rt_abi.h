@@ -284,7 +284,23 @@ int rt_destroy(rt_ctx* ctx);
  *   RT_OPT_MIN_CHUNK_SPP (RT_MIN_CHUNK_SPP; 1..65536, default 0 = chosen per launch):
  *     fewest samples of a tile that make one work item.
  *   RT_OPT_LAST_CHUNK_SPP (RT_STACK_LAST_SPP; 1..65536, default 4): the stack kernel's
- *     last sample chunk of a tile is halved down to parts of this many samples. */
+ *     last sample chunk of a tile is halved down to parts of this many samples.
+ *   RT_OPT_POOL_SLOTS (RT_POOL_SLOTS; 0 or 64..512, default 0): with a value from 64
+ *     on, scenes on the per-lane stack traversal keep that many paths per wave in a
+ *     pool (64-byte records in a region of global memory of the wave's own, queues of
+ *     slot numbers in LDS) and run every phase of the sample loop (tree walk, shading,
+ *     Texture::value) for a full wave of them; 0, the default, is the kernel that
+ *     keeps a path in one lane from start to end, which is the faster one on every
+ *     scene measured (the pool buys fuller waves with two more memory round trips
+ *     per ray and fewer resident waves).
+ *   RT_OPT_SHADE_BATCH (RT_SHADE_BATCH; 1..64, default 64), RT_OPT_TEX_BATCH
+ *     (RT_TEX_BATCH; 1..64, default 24): paths waiting that make a wave of the pool
+ *     kernel run its shading / texture code; RT_OPT_REFILL_LANES (RT_REFILL_LANES;
+ *     1..64, default 16): finished walks that make it hand them over and take new rays;
+ *     RT_OPT_HUNGRY_LANES (RT_HUNGRY_LANES; 1..64, default 8): idle lanes, with no ray
+ *     waiting, that make it run a waiting batch of any size.
+ * None of these changes which paths are traced or what they return: a pixel's sum
+ * changes at most in the order of its fp32 additions. */
 #define RT_OPT_FIXED_ORDER 1
 #define RT_OPT_READY_LANES 2
 #define RT_OPT_HOLD_LANES 3
@@ -293,6 +309,11 @@ int rt_destroy(rt_ctx* ctx);
 #define RT_OPT_ITEM_ROUNDS 6
 #define RT_OPT_MIN_CHUNK_SPP 7
 #define RT_OPT_LAST_CHUNK_SPP 8
+#define RT_OPT_POOL_SLOTS 9
+#define RT_OPT_SHADE_BATCH 10
+#define RT_OPT_REFILL_LANES 11
+#define RT_OPT_TEX_BATCH 12
+#define RT_OPT_HUNGRY_LANES 13
 int rt_set_option(rt_ctx* ctx, int option, int value);
 int rt_get_option(const rt_ctx* ctx, int option, int* value_out);
 

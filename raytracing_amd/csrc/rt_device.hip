@@ -1499,6 +1499,91 @@ __device__ __forceinline__ F3 texture_value(const rt_texture* __restrict__ textu
   return f3(0, 0, 0);
 }
 
+// Perlin::turb(p, 7) for the lanes in `need`, computed by the WHOLE wave one point at a time: 7 octaves x 8 lattice
+// corners are 56 independent terms, so lane 8*o + c takes corner c (di, dj, dk = the bits of c, perlin_noise's loop
+// order) of octave o and the point costs two rounds of table reads in all, where one lane walking the octaves alone
+// makes twenty-eight rounds one after the other while the rest of the wave waits for it (textured vertices are rare:
+// two or three lanes of a wave at a time).  The terms are added in perlin_noise's and perlin_turb's own order (corner
+// sums on lane 8*o, then the octaves), so the value equals perlin_turb's bit for bit.  Must be called by all 64 lanes.
+__device__ __forceinline__ float perlin_turb_wave(const rt_perlin* __restrict__ perlins, bool need, int perlin_index, F3 p) {
+  const int lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0));
+  const int o = lane >> 3;  // (lanes 56..63 would be an eighth octave: computed, never used)
+  const int di = (lane >> 2) & 1, dj = (lane >> 1) & 1, dk = lane & 1;
+  const float scale = __int_as_float((127 + o) << 23);  // 2^o: perlin_turb doubles p once per octave
+  float result = 0.0f;
+  unsigned long long m = __ballot(need);
+  while (m != 0ull) {
+    const int src = (int)__builtin_ctzll(m);
+    m &= m - 1ull;
+    const float px = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p.x), src));
+    const float py = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p.y), src));
+    const float pz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p.z), src));
+    const int pi = __builtin_amdgcn_readlane(perlin_index, src);
+    const __attribute__((address_space(1))) rt_perlin* pn = (const __attribute__((address_space(1))) rt_perlin*)(perlins + pi);
+    const float qx = px * scale, qy = py * scale, qz = pz * scale;
+    const float fx = floorf(qx), fy = floorf(qy), fz = floorf(qz);
+    const float u = qx - fx, v = qy - fy, w = qz - fz;
+    const unsigned i = perlin_cell(fx), j = perlin_cell(fy), k = perlin_cell(fz);
+    const float uu = u * u * (3.0f - 2.0f * u);
+    const float vv = v * v * (3.0f - 2.0f * v);
+    const float ww = w * w * (3.0f - 2.0f * w);
+    const int idx = pn->perm_x[(i + di) & 255u] ^ pn->perm_y[(j + dj) & 255u] ^ pn->perm_z[(k + dk) & 255u];
+    const __attribute__((address_space(1))) float* c = pn->ranvec[idx & 255];
+    const float wi = di ? uu : 1.0f - uu, wj = dj ? vv : 1.0f - vv, wk = dk ? ww : 1.0f - ww;
+    const float term = wi * wj * wk * (c[0] * (u - (float)di) + c[1] * (v - (float)dj) + c[2] * (w - (float)dk));
+    // perlin_noise: accum = 0; accum += term(corner 0), ... term(corner 7), on the first lane of each octave's eight
+    float noise = 0.0f + term;
+#pragma unroll
+    for (int cnr = 1; cnr < 8; ++cnr) noise += __shfl(term, (lane & ~7) + cnr, 64);
+    // perlin_turb: accum += weight * noise, the weight halving per octave
+    float accum = 0.0f, weight = 1.0f;
+#pragma unroll
+    for (int oct = 0; oct < 7; ++oct) {
+      accum += weight * __int_as_float(__builtin_amdgcn_readlane(__float_as_int(noise), 8 * oct));
+      weight *= 0.5f;
+    }
+    result = lane == src ? fabsf(accum) : result;
+  }
+  return result;
+}
+
+// Texture::value for the lanes in `need` (the others get an unspecified colour).  Must be called by all 64 lanes: the
+// checker chain is followed per lane, the turbulence of the noise textures is made by the whole wave when few lanes
+// need it (perlin_turb_wave) and by each lane for itself when many do.
+__device__ __forceinline__ F3 texture_value_wave(const rt_texture* __restrict__ textures, const rt_perlin* __restrict__ perlins, bool need, int tex, F3 p) {
+  F3 col = f3(0, 0, 0);
+  bool open = need, noise = false;
+  float scale = 0.0f;
+  int perlin_index = 0;
+  for (int level = 0; level < 8 && __ballot(open) != 0ull; ++level) {
+    if (open) {
+      const rt_texture t = textures[tex];
+      if (t.type == RT_TEX_CHECKER) {
+        const float sines = fast_sin(10.0f * p.x) * fast_sin(10.0f * p.y) * fast_sin(10.0f * p.z);
+        tex = sines < 0.0f ? t.odd : t.even;
+      } else {
+        open = false;
+        noise = t.type == RT_TEX_NOISE;
+        scale = t.scale;
+        perlin_index = t.perlin;
+        col = f3(t.color[0], t.color[1], t.color[2]);
+      }
+    }
+  }
+  const unsigned long long m_noise = __ballot(noise);
+  if (m_noise != 0ull) {
+    float turb = 0.0f;
+    if (__popcll(m_noise) <= 12) {
+      turb = perlin_turb_wave(perlins, noise, perlin_index, p);
+    } else if (noise) {
+      turb = perlin_turb(perlins + perlin_index, p, 7);
+    }
+    const float g = 0.5f * (1.0f + fast_sin(scale * p.z + 10.0f * turb));
+    col = sel3(noise, f3(g, g, g), col);
+  }
+  return col;
+}
+
 // reflect / refract / schlick of material.rs:162-180 (commented out in the reference).
 __device__ __forceinline__ F3 reflect3(F3 v, F3 n) {
   const float k = 2.0f * dot3(v, n);
@@ -1756,6 +1841,12 @@ struct RenderArgs {
   int hold_lanes;           // and lanes holding a leaf (in 64 traversing ones) that make the wave run the leaf code
   int accumulate;           // render_stack_kernel: items ADD their tile sums to the (zeroed) output instead of writing partial images
   int max_slots;            // render_stack_kernel: work items a wave may have open at once (1: a pixel's sum does not depend on scheduling)
+  int pool_slots;           // render_pool_kernel: path slots per wave (0: the launch uses render_stack_kernel)
+  void* pool_mem;           //   pool_slots 64-byte records for every wave of the grid
+  int refill_lanes;         //   finished walks in a wave that make it hand them over and take new rays
+  int shade_batch;          //   paths waiting to be shaded (or started) that make the wave run the shading code
+  int tex_batch;            //   paths waiting for a Texture::value that make the wave run the texture code
+  int hungry_lanes;         //   idle lanes, with the ray queue empty, that make the wave run a batch of any size
   int stack_lds;            // render_stack_kernel: entries of a lane's stack kept in LDS; deeper ones go to stack_ovf
   unsigned* stack_ovf;      // (scene's stack depth - stack_lds) x 128 dwords for every wave of the grid
 };
@@ -1891,8 +1982,8 @@ __global__ void __launch_bounds__(64, (TRAV == TRAV_STACK && GENERAL < 2) ? 6 : 
       // across a call has to sit in the registers the callee preserves.  The vertex used colour (1,1,1); a path that
       // went on gets its weight multiplied now, one that ended on a textured light adds its sample now. ----
       if (__ballot(pend >= 0) != 0ull) {
+        const F3 c = texture_value_wave(S.textures, S.perlins, pend >= 0, pend >= 0 ? S.materials[pend >> 1].texture : 0, ro);
         if (pend >= 0) {
-          const F3 c = texture_value(S.textures, S.perlins, S.materials[pend >> 1].texture, ro);
           const F3 v = f3(thr.x * c.x, thr.y * c.y, thr.z * c.z);
           if (pend & 1) {
             const float r = v.x != v.x ? 0.0f : v.x, g = v.y != v.y ? 0.0f : v.y, b = v.z != v.z ? 0.0f : v.z;  // de_nan
@@ -2201,8 +2292,9 @@ __global__ void __launch_bounds__(64, GENERAL < 2 ? RT_STACK_WAVES : 5) render_s
     if (GENERAL >= 2 && S.textured) {
       // Texture::value of the vertex before (see render_kernel): evaluated where little else is live.
       if (__ballot(ready & (pend >= 0)) != 0ull) {
-        if (ready & (pend >= 0)) {
-          const F3 c = texture_value(S.textures, S.perlins, S.materials[pend >> 1].texture, ro);
+        const bool tex_now = ready & (pend >= 0);
+        const F3 c = texture_value_wave(S.textures, S.perlins, tex_now, tex_now ? S.materials[pend >> 1].texture : 0, ro);
+        if (tex_now) {
           const F3 v = f3(thr.x * c.x, thr.y * c.y, thr.z * c.z);
           if (pend & 1) {
             const float cr = v.x != v.x ? 0.0f : v.x, cg = v.y != v.y ? 0.0f : v.y, cb = v.z != v.z ? 0.0f : v.z;  // de_nan
@@ -2479,6 +2571,538 @@ __global__ void __launch_bounds__(64, GENERAL < 2 ? RT_STACK_WAVES : 5) render_s
 }
 
 // ---------------------------------------------------------------------------
+// render_pool_kernel: the sample loop for scenes on the per-lane stack traversal,
+// with the wave's paths kept in a pool of records and handed between the phases
+// of the loop through queues, so that every phase runs on a full wave.
+//
+// render_stack_kernel keeps a path in one lane from its camera ray to its end, so
+// the lanes of a wave are in different phases at any moment (walking the tree,
+// holding a leaf, waiting to be shaded) and each phase's code runs for a fraction
+// of the wave.  Here a wave owns P path slots (more than its 64 lanes), each a
+// 64-byte record (ray, hit, weight, pixel, sample, depth) in a region of global
+// memory that only this wave touches, and four queues of slot numbers in LDS:
+//   ray queue      paths with a ray to trace;
+//   shade queue    paths whose walk has ended (hit found or missed);
+//   texture queue  paths waiting for a Texture::value (checker / noise);
+//   free queue     slots without a path.
+// A lane is only a place where a walk runs: it takes a ray from the ray queue,
+// walks the tree (trav_step / trav_leaf; the walk's stack and best hit live in the
+// lane as before), writes the hit into the record, puts the slot on the shade
+// queue and takes the next ray.  When the shade queue holds a wave's worth of paths
+// the wave runs the shading code (media, Philox, color(), a new camera path for
+// each one that ended, the root's box test of the next ray) once for 64 of them,
+// and they go to the ray queue; the walks the lanes were in wait in their
+// registers meanwhile.  Texture::value runs the same way for a batch of textured
+// vertices.  The queues and records are the wave's own: no atomics, no barriers,
+// and what a wave computes does not depend on what other waves do.
+// Work items, tile accumulators and the way a tile's sums reach the output are
+// render_stack_kernel's.
+// ---------------------------------------------------------------------------
+struct __align__(16) PoolRec {
+  float ox, oy, oz, t;   // ray origin; after the walk: distance of the hit
+  float dx, dy, dz;      // ray direction
+  int ref;               // waiting for a lane: the reference the walk starts at (the root's box test is made by the
+                         // shading code); after the walk: the primitive hit, -1 for none
+  float tr, tg, tb;      // the path's weight
+  unsigned depth_pix;    // depth << 8 | item slot * 64 + pixel within the tile
+  unsigned pixel_id, sample;
+  int pend;              // a colour still to come from Texture::value: material index << 1 | ended-on-a-light, or -1
+  int pad;
+};
+static_assert(sizeof(PoolRec) == 64, "four 16-byte loads");
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(1))) f32x4 glb_f4;  // (global_ loads and stores, not flat_ ones: see LaneStackT)
+typedef __attribute__((address_space(1))) float glb_f32;
+typedef __attribute__((address_space(1))) char glb_char;
+#define RT_POOL_LDS_DWORDS(P) (4 * (P))  // the four queues
+template <bool STATS, bool SUMSQ, int GENERAL>
+__global__ void __launch_bounds__(64, GENERAL < 2 ? 5 : 4) render_pool_kernel(DevScene S, DevCamera cam, RenderArgs A, float* __restrict__ out_sum,
+                                                            float* __restrict__ out_sumsq, unsigned long long* __restrict__ stats, unsigned* __restrict__ queue) {
+  __shared__ float acc[SUMSQ ? 6 : 3][RT_SLOTS * 64];
+  __shared__ int slot_info[RT_SLOTS][4];  // tile x, tile y, chunk
+  __shared__ float cam_lds[20];
+  extern __shared__ float4 prim_lds[];  // A.stack_lds stack entries of 64 lanes, then the four queues
+  const int lane = threadIdx.x & 63;
+  LaneStackT<true> stk;
+  stk.lds = (lds_u32*)((unsigned*)prim_lds + lane);
+  stk.n_lds = A.stack_lds;
+  stk.ovf = (glb_u32*)(A.stack_ovf + (size_t)blockIdx.x * (size_t)(S.stack_depth - A.stack_lds) * 128 + lane);
+  const int P = A.pool_slots;
+  glb_char* const recs = (glb_char*)A.pool_mem + (size_t)blockIdx.x * (size_t)P * sizeof(PoolRec);  // this wave's records
+  lds_u32* const ray_q = (lds_u32*)((unsigned*)prim_lds + A.stack_lds * 128);
+  lds_u32* const shade_q = ray_q + P;
+  lds_u32* const tex_q = shade_q + P;
+  lds_u32* const free_q = tex_q + P;
+  for (int k = lane; k < P; k += 64) free_q[k] = (unsigned)k;
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      cam_lds[k] = cam.origin[k];
+      cam_lds[3 + k] = cam.llc[k];
+      cam_lds[6 + k] = cam.horizontal[k];
+      cam_lds[9 + k] = cam.vertical[k];
+      cam_lds[12 + k] = cam.u[k];
+      cam_lds[15 + k] = cam.v[k];
+    }
+    cam_lds[18] = cam.lens_radius;
+  }
+  const bool has_lens = cam.lens_radius != 0.0f;
+  const float4* dprim_tab = (const float4*)S.dprims;
+  Counters cnt;
+  memset(&cnt, 0, sizeof(cnt));
+  const int n_tiles = A.n_tiles;
+  const int n_items = n_tiles * A.n_chunks;
+  float a_t_min = A.t_min;
+  int a_max_depth = A.max_depth, a_sky = A.sky;
+  int a_hold = A.hold_lanes, a_refill = A.refill_lanes, a_shade = A.shade_batch, a_tex = A.tex_batch, a_hungry = A.hungry_lanes;
+  int slots_cap = A.max_slots < RT_SLOTS ? A.max_slots : RT_SLOTS;
+  asm volatile("" : "+s"(a_t_min), "+s"(a_max_depth), "+s"(a_sky), "+s"(a_hold), "+s"(a_refill), "+s"(a_shade), "+s"(a_tex), "+s"(a_hungry), "+s"(slots_cap));
+  int idle_trips = 0;
+#ifdef RT_PHASE_TIMING
+  unsigned long long ph[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long t_last = __builtin_amdgcn_s_memtime();
+#endif
+  // The queues: rings of P entries each; heads and counts are the same for all lanes (scalar registers).
+  int ray_head = 0, ray_n = 0, shade_head = 0, shade_n = 0, tex_head = 0, tex_n = 0, free_head = 0, free_n = P;
+  // appends the slots of the lanes with `mine` to a ring (a slot is in one queue at a time, so a ring never overflows)
+#define RT_RING_PUSH(q, head, n, mine, id)                                                                          \
+  do {                                                                                                              \
+    const unsigned long long m_ = __ballot(mine);                                                                   \
+    if (m_ != 0ull) {                                                                                               \
+      const int rank_ = __builtin_amdgcn_mbcnt_hi((unsigned)(m_ >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m_, 0)); \
+      if (mine) {                                                                                                   \
+        int at_ = (head) + (n) + rank_;                                                                             \
+        at_ -= at_ >= P ? P : 0;                                                                                    \
+        q[at_] = (unsigned)(id);                                                                                    \
+      }                                                                                                             \
+      (n) += __popcll(m_);                                                                                          \
+    }                                                                                                               \
+  } while (0)
+  // Wave-uniform state of the open work items (see render_stack_kernel); live[d]: paths of slot d's item still on their way.
+  unsigned open_mask = 0;
+  int f = 0;
+  bool fill_open = false, queue_empty = false, items_dirty = true;
+  int tx = 0, ty = 0;
+  int s_first = 0, pool_size = 0, pool_next = 0;
+  int live[RT_SLOTS];
+#pragma unroll
+  for (int d = 0; d < RT_SLOTS; ++d) live[d] = 0;
+
+  // Per-lane state: the walk this lane runs, and the slot of the path it belongs to (-1: none).
+  int slot = -1;
+  bool trav = false;
+  Trav T;
+  T.r = make_ray(f3(0, 0, 0), f3(1, 1, 1));
+  T.sp = 0;
+  T.cur = TRAV_POP;
+  T.best.t = INFINITY;
+  T.best.prim = -1;
+
+  for (;;) {
+    // ======================= work items (wave-uniform), after a pass that may have ended or started paths =======================
+    if (items_dirty) {
+      items_dirty = false;
+      if (fill_open && pool_next >= pool_size) fill_open = false;  // slot f goes on as a draining slot
+      unsigned draining = open_mask & ~(fill_open ? (1u << f) : 0u);
+      while (draining != 0u) {
+        const int d = __builtin_ctz(draining);
+        draining &= draining - 1u;
+        int live_d = 0;
+#pragma unroll
+        for (int e = 0; e < RT_SLOTS; ++e) live_d = e == d ? live[e] : live_d;
+        if (live_d != 0) continue;
+        // the last path of this item has ended: write its tile (main.rs:112-114; sums, not means)
+        const int dtx = slot_info[d][0], dty = slot_info[d][1], chunk = slot_info[d][2];
+        const size_t slab = A.accumulate ? 0 : (size_t)chunk * A.nx * A.ny * 3;
+        const int px = dtx * 8 + (lane & 7);
+        const int row = dty * 8 + (lane >> 3);
+        if (px < A.nx && row < A.ny) {
+          const size_t at = slab + ((size_t)row * A.nx + px) * 3;
+          if (A.accumulate) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) unsafeAtomicAdd(&out_sum[at + c], acc[c][d * 64 + lane]);
+            if (SUMSQ) {
+#pragma unroll
+              for (int c = 0; c < 3; ++c) unsafeAtomicAdd(&out_sumsq[at + c], acc[3 + c][d * 64 + lane]);
+            }
+          } else {
+            out_sum[at] = acc[0][d * 64 + lane];
+            out_sum[at + 1] = acc[1][d * 64 + lane];
+            out_sum[at + 2] = acc[2][d * 64 + lane];
+            if (SUMSQ) {
+              out_sumsq[at] = acc[3][d * 64 + lane];
+              out_sumsq[at + 1] = acc[4][d * 64 + lane];
+              out_sumsq[at + 2] = acc[5][d * 64 + lane];
+            }
+          }
+        }
+        open_mask &= ~(1u << d);
+      }
+      if (!fill_open && !queue_empty && __popc(open_mask) < slots_cap) {
+        int item = 0;
+        if (lane == 0) item = (int)atomicAdd(queue, 1u);
+        item = __builtin_amdgcn_readfirstlane(item);
+        if (item >= n_items) {
+          queue_empty = true;
+        } else {
+          f = __builtin_ctz(~open_mask);
+          const int chunk = item / n_tiles;
+          const int tile = item - chunk * n_tiles;
+          tx = tile % A.tiles_x;
+          ty = tile / A.tiles_x;
+          bool mine = true;
+          if (A.shard_count > 1) {
+            const int t = A.shard_index + tile * A.shard_count;
+            tx = t % A.shard_width;
+            ty = t / A.shard_width;
+            mine = (tx < A.tiles_x) & (ty < A.tiles_y);
+          }
+#pragma unroll
+          for (int c = 0; c < (SUMSQ ? 6 : 3); ++c) acc[c][f * 64 + lane] = 0.0f;
+          if (lane == 0) {
+            slot_info[f][0] = tx;
+            slot_info[f][1] = ty;
+            slot_info[f][2] = chunk;
+          }
+          const int n_whole = A.n_chunks - A.split_parts;
+          int s_len = A.chunk_spp;
+          s_first = chunk * A.chunk_spp;
+          if (chunk >= n_whole) {
+            const int k = chunk - n_whole;
+            const int last = A.spp - n_whole * A.chunk_spp;
+            const int o0 = last - (last >> k);
+            const int o1 = k + 1 < A.split_parts ? last - (last >> (k + 1)) : last;
+            s_first = n_whole * A.chunk_spp + o0;
+            s_len = o1 - o0;
+          }
+          pool_size = mine ? 64 * s_len : 0;
+          pool_next = 0;
+          open_mask |= 1u << f;
+          fill_open = true;
+          items_dirty = pool_size == 0;  // (an item beyond the image's edge: closed again on the next trip)
+#pragma unroll
+          for (int e = 0; e < RT_SLOTS; ++e) live[e] = e == f ? 0 : live[e];
+        }
+      }
+      RT_STAMP(4);  // work items
+    }
+
+    const int n_trav = __popcll(__ballot(trav));
+    // The ray queue is empty and lanes stand idle: the fuller of the two waiting batches runs now, whatever its size.
+    const bool hungry = ray_n == 0 && n_trav <= 64 - a_hungry;
+    const int spawn_room = fill_open ? pool_size - pool_next : 0;
+    const int spawnable = free_n < spawn_room ? free_n : spawn_room;
+    const int shadable = shade_n + spawnable;
+    unsigned key0 = A.key0, key1 = A.key1;
+    asm volatile("" : "+s"(key0), "+s"(key1));
+
+    if (shadable >= a_shade || (hungry && shadable > 0 && shadable >= tex_n)) {
+      // ======================= shading: color() for up to 64 paths of the shade queue; new paths for ended ones and free slots =======================
+      idle_trips = 0;
+      items_dirty = true;
+      const int k_rec = shade_n < 64 ? shade_n : 64;
+      const bool act = lane < k_rec;
+      int my = -1;
+      {
+        int at = shade_head + (act ? lane : 0);
+        at -= at >= P ? P : 0;
+        const int id = (int)shade_q[at];
+        my = act ? id : -1;
+        shade_head += k_rec;
+        shade_head -= shade_head >= P ? P : 0;
+        shade_n -= k_rec;
+      }
+      int n_grab = 64 - k_rec;
+      n_grab = n_grab < spawnable ? n_grab : spawnable;
+      const bool grab = (lane >= k_rec) & (lane < k_rec + n_grab);
+      {
+        int at = free_head + (grab ? lane - k_rec : 0);
+        at -= at >= P ? P : 0;
+        const int id = (int)free_q[at];
+        my = grab ? id : my;
+        free_head += n_grab;
+        free_head -= free_head >= P ? P : 0;
+        free_n -= n_grab;
+      }
+      RT_COUNT(8, 1); RT_COUNT(9, k_rec);
+      glb_f4* const rec = (glb_f4*)(recs + ((unsigned)(my >= 0 ? my : 0) << 6));
+      const f32x4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3];
+      F3 ro = f3(q0.x, q0.y, q0.z);
+      F3 rd = sel3(act, f3(q1.x, q1.y, q1.z), f3(1.0f, 1.0f, 1.0f));
+      Hit h;
+      h.t = q0.w;
+      h.prim = act ? __float_as_int(q1.w) : -1;
+      F3 thr = f3(q2.x, q2.y, q2.z);
+      const unsigned dp = act ? __float_as_uint(q2.w) : 0u;
+      unsigned pixel_id = __float_as_uint(q3.x), sample = __float_as_uint(q3.y);
+      int depth = (int)(dp >> 8), pix = (int)(dp & 255u);
+      const RayF ray = make_ray(ro, rd);
+      // what is left of world.hit: the ConstantMedium nodes (they draw random numbers)
+      if (GENERAL != 0 && S.n_scan > 0) {
+        const PathRng rng = {pixel_id, sample, (unsigned)depth, key0, key1};
+        scan_range<STATS, true, true, 0>(S, 0, S.n_scan, act, ray, a_t_min, INFINITY, rng, h, cnt);
+      }
+      RT_STAMP(1);  // media
+      const U4 w = philox4x32_10(pixel_id, sample, (unsigned)depth, 0u, key0, key1);
+      const Shaded sh = shade_vertex<STATS, GENERAL>(S, dprim_tab, act, h, ray, thr, depth, w, a_max_depth, a_sky, pixel_id, sample, key0, key1, cnt);
+      RT_STAMP(2);  // philox + shade
+      const bool go_on = act & sh.scattered & ((sh.thr_next.x > 0.0f) | (sh.thr_next.y > 0.0f) | (sh.thr_next.z > 0.0f));
+      const bool done = act & !go_on;
+      if (done) {
+        // de_nan (main.rs:252-264) then col += (main.rs:108)
+        const float cr = sh.radiance.x != sh.radiance.x ? 0.0f : sh.radiance.x;
+        const float cg = sh.radiance.y != sh.radiance.y ? 0.0f : sh.radiance.y;
+        const float cb = sh.radiance.z != sh.radiance.z ? 0.0f : sh.radiance.z;
+        if (cr != 0.0f || cg != 0.0f || cb != 0.0f) {
+          atomicAdd(&acc[0][pix], cr);
+          atomicAdd(&acc[1][pix], cg);
+          atomicAdd(&acc[2][pix], cb);
+          if (SUMSQ) {
+            atomicAdd(&acc[3][pix], cr * cr);
+            atomicAdd(&acc[4][pix], cg * cg);
+            atomicAdd(&acc[5][pix], cb * cb);
+          }
+        }
+      }
+      // A checker or noise texture's colour comes from the texture pass (the vertex used white): the path waits in the
+      // texture queue, with the hit point where its next ray starts, and a path that ended on a textured light keeps
+      // its weight and its slot until its sample has been added there.
+      int pend = -1;
+      if (GENERAL >= 2) {
+        const bool lit = sh.textured & sh.emits;
+        pend = (act & sh.textured & (go_on | sh.emits)) ? ((sh.mat_index << 1) | (lit ? 1 : 0)) : -1;
+        thr = sel3(act, sel3(lit, thr, sh.thr_next), thr);
+      } else {
+        thr = sel3(act, sh.thr_next, thr);
+      }
+      ro = sel3(act, sh.p, ro);
+      rd = sel3(go_on, sh.dir, rd);
+      depth += go_on ? 1 : 0;
+      const bool to_tex = GENERAL >= 2 && pend >= 0;
+      const bool ended = done & !to_tex;
+#pragma unroll
+      for (int e = 0; e < RT_SLOTS; ++e) live[e] -= __popcll(__ballot(ended & ((pix >> 6) == e)));
+      RT_STAMP(3);  // deposit + state update
+      // ---- (pixel, sample) paths for the slots whose path ended and for the free slots taken above (main.rs:96-101) ----
+      const bool cand = ended | grab;
+      const unsigned long long need = __ballot(cand);
+      bool start = false;
+      int fresh_px = 0, fresh_j = 0;
+      if (need != 0ull && fill_open && pool_next < pool_size) {
+        const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(need >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)need, 0));
+        const int k = pool_next + rank;
+        pool_next += __popcll(need);
+        const bool take = cand & (k < pool_size);
+        const int kk = take ? k : 0;
+        const int c_pix = kk & 63;
+        const int px = tx * 8 + (c_pix & 7);
+        const int row = ty * 8 + (c_pix >> 3);
+        start = take & (px < A.nx) & (row < A.ny);
+        pix = start ? (f * 64 + c_pix) : pix;
+        pixel_id = start ? (unsigned)((A.ny - 1 - row) * A.nx + px) : pixel_id;
+        sample = start ? (unsigned)(A.sample_begin + s_first + (kk >> 6)) : sample;
+        depth = start ? 0 : depth;
+        thr = sel3(start, f3(1.0f, 1.0f, 1.0f), thr);
+        fresh_px = px;
+        fresh_j = A.ny - 1 - row;
+        if (STATS) cnt.paths += start;
+#pragma unroll
+        for (int e = 0; e < RT_SLOTS; ++e) live[e] += e == f ? __popcll(__ballot(start)) : 0;
+      }
+      // ---- camera ray of the new paths (main.rs:102-105, camera.rs:53-62); word 0 of the vertex's Philox call ----
+      if (__ballot(start) != 0ull) {
+        const U4 cw = philox4x32_10(pixel_id, sample, 0u, 0u, key0, key1);
+        const float u = ((float)fresh_px + (float)(cw.x >> 16) * (1.0f / 65536.0f)) * A.inv_nx;
+        const float v = ((float)fresh_j + (float)(cw.x & 0xffffu) * (1.0f / 65536.0f)) * A.inv_ny;
+        int c0 = 0;
+        asm volatile("" : "+v"(c0));
+        const float* cl = cam_lds + c0;
+        float rdx = 0.0f, rdy = 0.0f;
+        F3 offset = f3(0.0f, 0.0f, 0.0f);
+        if (has_lens) {
+          const float lens_radius = cl[18];
+          unsigned attempt = 0;
+          bool looking = start;
+          while (__ballot(looking) != 0ull) {
+            const U4 lw = philox4x32_10(pixel_id, sample, 0u, 1u + attempt, key0, key1);
+            const float dx = 2.0f * u01(lw.x) - 1.0f, dy = 2.0f * u01(lw.y) - 1.0f;
+            const bool ok = looking & (fmaf(dy, dy, dx * dx) < 1.0f);
+            rdx = ok ? lens_radius * dx : rdx;
+            rdy = ok ? lens_radius * dy : rdy;
+            looking &= !ok;
+            ++attempt;
+          }
+          offset = f3(fmaf(cl[15], rdy, cl[12] * rdx), fmaf(cl[16], rdy, cl[13] * rdx), fmaf(cl[17], rdy, cl[14] * rdx));
+        }
+        const F3 org = f3(cl[0] + offset.x, cl[1] + offset.y, cl[2] + offset.z);
+        const F3 dir = f3(fmaf(v, cl[9], fmaf(u, cl[6], cl[3])) - cl[0] - offset.x,
+                          fmaf(v, cl[10], fmaf(u, cl[7], cl[4])) - cl[1] - offset.y,
+                          fmaf(v, cl[11], fmaf(u, cl[8], cl[5])) - cl[2] - offset.z);
+        ro = sel3(start, org, ro);
+        rd = sel3(start, dir, rd);
+      }
+      // ---- the root's own box test of the next ray (bvh.rs:198), made here for the whole batch: a lane that takes
+      // the ray starts at the reference it gives; then the records go back and the slots to their next queue ----
+      const bool to_ray = (go_on & !to_tex) | start;
+      const bool keeps = to_ray | to_tex;
+      rd = sel3(keeps, rd, f3(1.0f, 1.0f, 1.0f));
+      Counters c2;  // (counted where a lane takes the ray)
+      memset(&c2, 0, sizeof(c2));
+      const int first = trav_enter<STATS>(S, S.root_ref, 0, make_ray(ro, rd), a_t_min, INFINITY, c2);
+      if (keeps) {
+        rec[0] = (f32x4){ro.x, ro.y, ro.z, 0.0f};
+        rec[1] = (f32x4){rd.x, rd.y, rd.z, __int_as_float(first)};
+        rec[2] = (f32x4){thr.x, thr.y, thr.z, __uint_as_float(((unsigned)depth << 8) | (unsigned)pix)};
+        rec[3] = (f32x4){__uint_as_float(pixel_id), __uint_as_float(sample), __int_as_float(pend), 0.0f};
+      }
+      RT_RING_PUSH(ray_q, ray_head, ray_n, to_ray, my);
+      if (GENERAL >= 2) RT_RING_PUSH(tex_q, tex_head, tex_n, to_tex, my);
+      const bool to_free = (my >= 0) & !keeps;
+      RT_RING_PUSH(free_q, free_head, free_n, to_free, my);
+      // (the records are read again by other lanes of this wave: the stores are waited for here, once per batch)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      RT_STAMP(5);  // new paths, camera, root test, write-back
+      continue;
+    }
+
+    if (GENERAL >= 2 && (tex_n >= a_tex || (hungry && tex_n > 0))) {
+      // ======================= Texture::value (texture.rs:22-35) for up to 64 paths of the texture queue =======================
+      idle_trips = 0;
+      items_dirty = true;
+      const int k_rec = tex_n < 64 ? tex_n : 64;
+      const bool act = lane < k_rec;
+      int at = tex_head + (act ? lane : 0);
+      at -= at >= P ? P : 0;
+      const int my = (int)tex_q[at];
+      tex_head += k_rec;
+      tex_head -= tex_head >= P ? P : 0;
+      tex_n -= k_rec;
+      glb_f4* const rec = (glb_f4*)(recs + ((unsigned)(act ? my : 0) << 6));
+      const f32x4 q0 = rec[0], q2 = rec[2], q3 = rec[3];
+      const int pend = act ? __float_as_int(q3.z) : 0;
+      const int pix = (int)(__float_as_uint(q2.w) & 255u);
+      const bool lit = act & ((pend & 1) != 0);
+      const F3 c = texture_value_wave(S.textures, S.perlins, act, act ? S.materials[pend >> 1].texture : 0, f3(q0.x, q0.y, q0.z));
+      if (act) {
+        const F3 v = f3(q2.x * c.x, q2.y * c.y, q2.z * c.z);
+        if (lit) {
+          const float cr = v.x != v.x ? 0.0f : v.x, cg = v.y != v.y ? 0.0f : v.y, cb = v.z != v.z ? 0.0f : v.z;  // de_nan
+          if (cr != 0.0f || cg != 0.0f || cb != 0.0f) {
+            atomicAdd(&acc[0][pix], cr);
+            atomicAdd(&acc[1][pix], cg);
+            atomicAdd(&acc[2][pix], cb);
+            if (SUMSQ) {
+              atomicAdd(&acc[3][pix], cr * cr);
+              atomicAdd(&acc[4][pix], cg * cg);
+              atomicAdd(&acc[5][pix], cb * cb);
+            }
+          }
+        } else {
+          rec[2] = (f32x4){v.x, v.y, v.z, q2.w};
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < RT_SLOTS; ++e) live[e] -= __popcll(__ballot(lit & ((pix >> 6) == e)));
+      RT_RING_PUSH(ray_q, ray_head, ray_n, act & !lit, my);
+      RT_RING_PUSH(free_q, free_head, free_n, lit, my);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      RT_STAMP(0);  // texture
+      continue;
+    }
+
+    if (n_trav == 0 && ray_n == 0 && __ballot(slot >= 0) == 0ull) {
+      // Nothing to walk, to shade or to colour, and no path to start: every path of the open items has ended.  The
+      // item code at the top of the loop writes their tiles and opens the next item, or there is none left.
+      if (open_mask == 0u && queue_empty) break;
+      // (Every wave must leave this loop: a wave that finds nothing to do this many trips in a row, which the
+      // bookkeeping above rules out, gives up rather than spin.)
+      if (++idle_trips > 8) break;
+      items_dirty = true;
+      continue;
+    }
+    idle_trips = 0;
+
+    // ======================= traversal: hand-overs, steps and leaf rounds until a batch is due =======================
+    for (;;) {
+      // ---- finished walks are handed over and idle lanes take new rays: when enough walks have ended to make it
+      // worth a pass, when nothing else is walking, or when the ray queue is empty and lanes stand idle ----
+      const bool fin = !trav & (slot >= 0);
+      const unsigned long long m_fin = __ballot(fin);
+      const int n_trav0 = __popcll(__ballot(trav));
+      if (m_fin != 0ull && (__popcll(m_fin) >= a_refill || n_trav0 == 0 || (ray_n == 0 && 64 - n_trav0 >= a_hungry))) {
+        if (fin) {
+          glb_f32* const rec = (glb_f32*)(recs + ((unsigned)slot << 6));
+          rec[3] = T.best.t;
+          rec[7] = __int_as_float(T.best.prim);
+        }
+        RT_RING_PUSH(shade_q, shade_head, shade_n, fin, slot);
+        slot = fin ? -1 : slot;
+      }
+      const bool want = !trav & (slot < 0);
+      const unsigned long long m_want = __ballot(want);
+      int n_take = __popcll(m_want);
+      n_take = n_take < ray_n ? n_take : ray_n;
+      if (n_take > 0) {
+        const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(m_want >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m_want, 0));
+        const bool go = want & (rank < n_take);
+        if (go) {
+          int at = ray_head + rank;
+          at -= at >= P ? P : 0;
+          const int id = (int)ray_q[at];
+          const glb_f4* const rec = (const glb_f4*)(recs + ((unsigned)id << 6));
+          const f32x4 q0 = rec[0], q1 = rec[1];
+          // ---- world.hit(r, 0.001, INFINITY), main.rs:166: the walk starts where the root's box test sent it ----
+          T.r = make_ray(f3(q0.x, q0.y, q0.z), f3(q1.x, q1.y, q1.z));
+          T.cur = __float_as_int(q1.w);
+          T.sp = 0;
+          T.best.t = INFINITY;
+          T.best.prim = -1;
+          slot = id;
+          trav = true;
+          if (STATS) { cnt.rays++; cnt.node_tests++; }
+        }
+        ray_head += n_take;
+        ray_head -= ray_head >= P ? P : 0;
+        ray_n -= n_take;
+      }
+      RT_STAMP(5);  // hand-over
+      const unsigned long long m_trav1 = __ballot(trav);
+      if (m_trav1 == 0ull) break;
+      // a batch is due: the shade queue holds a wave's worth, or the ray queue is empty and lanes stand idle
+      if (shade_n + spawnable >= a_shade) break;
+      if (ray_n == 0 && __popcll(m_trav1) <= 64 - a_hungry && (shade_n + spawnable > 0 || tex_n > 0)) break;
+      RT_COUNT(10, 1); RT_COUNT(11, __popcll(m_trav1));
+      // one step for every lane that has one to make; a lane holding a list or instance leaf waits for the leaf code below
+      if (trav & !trav_holds_leaf(T.cur)) trav = trav_step<STATS>(S, stk, T, a_t_min, INFINITY, cnt);
+      RT_STAMP(6);  // step
+      const bool hold = trav & trav_holds_leaf(T.cur);
+      const unsigned long long m_trav = __ballot(trav), m_hold = __ballot(hold);
+      // the leaf code runs once for all lanes that hold a leaf, when enough of the traversing lanes do
+      if (m_hold != 0ull && __popcll(m_hold) * 64 >= a_hold * __popcll(m_trav)) {
+        RT_COUNT(12, 1); RT_COUNT(13, __popcll(m_hold)); RT_COUNT(14, __popcll(__ballot(hold & ((T.cur & BN2_PRIM) != 0))));
+        if (hold) trav_leaf<STATS>(S, stk, T, a_t_min, INFINITY, cnt);
+      }
+      RT_STAMP(7);  // leaf code
+    }
+  }
+#undef RT_RING_PUSH
+
+  if (STATS) {
+    const unsigned v[9] = {cnt.paths, cnt.rays, cnt.hits, cnt.node_tests, cnt.rect_tests, cnt.sphere_tests, cnt.instance_ops, cnt.shade_events, cnt.light_tests};
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      unsigned long long x = v[k];
+      for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off, 64);
+      if (lane == 0) atomicAdd(&stats[k], x);
+    }
+#ifdef RT_PHASE_TIMING
+    if (lane == 0)
+      for (int k = 0; k < 16; ++k) atomicAdd(&stats[16 + k], ph[k]);
+#endif
+  }
+}
+
+// ---------------------------------------------------------------------------
 // selftest_rcp_kernel: exact_rcp against the correctly rounded division for all
 // 2^32 inputs.  counts[0] = mismatching inputs, counts[1] = in-range inputs
 // whose Newton step alone (no fallback) mismatches, bad[0..15] = examples.
@@ -2550,7 +3174,7 @@ static __device__ __align__(256) unsigned char scratch[RT_NOALLOC_SCRATCH_BYTES]
 // ---------------------------------------------------------------------------
 // Host side of the ABI
 // ---------------------------------------------------------------------------
-#define RT_OPT_COUNT 9  // RT_OPT_* of rt_abi.h are 1..8
+#define RT_OPT_COUNT 14  // RT_OPT_* of rt_abi.h are 1..13
 struct rt_ctx {
   int device;
   bool has_scene;
@@ -2576,6 +3200,8 @@ struct rt_ctx {
   unsigned* d_queue;    // the work-item counter of render_kernel
   unsigned* d_stack_ovf;  // render_stack_kernel: the deep ends of the lanes' stacks (grown on demand)
   size_t stack_ovf_bytes;
+  void* d_pool;           // render_pool_kernel: the waves' path records (grown on demand)
+  size_t pool_bytes;
   int n_cus;
   float* d_slabs;       // partial-sum slabs of chunked renders, grown on demand
   size_t slab_floats;
@@ -2607,9 +3233,15 @@ const OptSpec kOptSpec[RT_OPT_COUNT] = {
     {1, 1000, 30, "RT_WANT_ROUNDS"},      // RT_OPT_ITEM_ROUNDS
     {0, 65536, 0, "RT_MIN_CHUNK_SPP"},    // RT_OPT_MIN_CHUNK_SPP (0: per launch)
     {1, 65536, RT_STACK_LAST_SPP, "RT_STACK_LAST_SPP"},  // RT_OPT_LAST_CHUNK_SPP
+    {0, 512, 0, "RT_POOL_SLOTS"},         // RT_OPT_POOL_SLOTS (0: render_stack_kernel; otherwise at least 64)
+    {1, 64, 64, "RT_SHADE_BATCH"},        // RT_OPT_SHADE_BATCH
+    {1, 64, 16, "RT_REFILL_LANES"},       // RT_OPT_REFILL_LANES
+    {1, 64, 24, "RT_TEX_BATCH"},          // RT_OPT_TEX_BATCH
+    {1, 64, 8, "RT_HUNGRY_LANES"},        // RT_OPT_HUNGRY_LANES
 };
 int clamp_opt(int option, int value) {
   const OptSpec& o = kOptSpec[option];
+  if (option == RT_OPT_POOL_SLOTS && value > 0 && value < 64) value = 64;  // (a pool holds a wave's worth of paths at least)
   return value < o.lo ? o.lo : (value > o.hi ? o.hi : value);
 }
 
@@ -3320,6 +3952,11 @@ int launch_render(rt_ctx* ctx, const rt_camera* cam, const rt_render_params* p, 
   // scenes with media or the older materials have the heavier shading phase: it is run for fuller waves
   A.ready_lanes = ctx->opt[RT_OPT_READY_LANES] > 0 ? ctx->opt[RT_OPT_READY_LANES] : (ctx->general != 0 ? 56 : RT_READY_LANES);
   A.hold_lanes = ctx->opt[RT_OPT_HOLD_LANES];
+  A.pool_slots = trav == TRAV_STACK ? ctx->opt[RT_OPT_POOL_SLOTS] : 0;
+  A.refill_lanes = ctx->opt[RT_OPT_REFILL_LANES];
+  A.shade_batch = ctx->opt[RT_OPT_SHADE_BATCH];
+  A.tex_batch = ctx->opt[RT_OPT_TEX_BATCH];
+  A.hungry_lanes = ctx->opt[RT_OPT_HUNGRY_LANES];
   float* k_sum = d_sum;
   float* k_sumsq = d_sumsq;
   unsigned* d_queue = no_alloc ? (unsigned*)ctx->scratch_ptr : ctx->d_queue;
@@ -3385,6 +4022,30 @@ int launch_render(rt_ctx* ctx, const rt_camera* cam, const rt_render_params* p, 
       }
       A.stack_ovf = ctx->d_stack_ovf;
     }
+    // the pool kernel's path records: pool_slots x 64 bytes for every wave of the grid
+    A.pool_mem = nullptr;
+    if (A.pool_slots > 0) {
+      const size_t pool_bytes = (size_t)waves * (size_t)A.pool_slots * sizeof(PoolRec);
+      if (no_alloc) {
+        // after the stack regions in the static scratch, if there is room; otherwise this launch takes the kernel without a pool
+        size_t at = RT_NOALLOC_SLAB_OFFSET;
+        if (!A.accumulate && A.n_chunks > 1) at += (size_t)A.n_chunks * per_image * sizeof(float);
+        at = (at + 255) & ~(size_t)255;
+        at += (size_t)waves * (size_t)(ctx->dev.stack_depth - A.stack_lds) * 128 * sizeof(unsigned);
+        at = (at + 255) & ~(size_t)255;
+        if (at + pool_bytes <= RT_NOALLOC_SCRATCH_BYTES) A.pool_mem = ctx->scratch_ptr + at;
+        else A.pool_slots = 0;
+      } else {
+        if (pool_bytes > ctx->pool_bytes) {
+          if (ctx->d_pool) HIP_TRY(hipFree(ctx->d_pool));
+          ctx->d_pool = nullptr;
+          ctx->pool_bytes = 0;
+          HIP_TRY(hipMalloc(&ctx->d_pool, pool_bytes));
+          ctx->pool_bytes = pool_bytes;
+        }
+        A.pool_mem = ctx->d_pool;
+      }
+    }
   }
   typedef void (*RenderFn)(DevScene, DevCamera, RenderArgs, float*, float*, unsigned long long*, unsigned*);
 #define RT_TRIO(ST, SQ, TR) render_kernel<ST, SQ, TR, 0>, render_kernel<ST, SQ, TR, 1>, render_kernel<ST, SQ, TR, 2>, render_kernel<ST, SQ, TR, 3>
@@ -3398,8 +4059,13 @@ int launch_render(rt_ctx* ctx, const rt_camera* cam, const rt_render_params* p, 
   RenderFn fn = table[(stats ? 24 : 0) + (d_sumsq ? 12 : 0) + trav * 4 + ctx->general];
   // scenes on the per-lane stack traversal: the kernel that keeps a lane's traversal going across the shading code
   if (trav == TRAV_STACK) fn = stack_table[(stats ? 8 : 0) + (d_sumsq ? 4 : 0) + ctx->general];
+#define RT_POOL(ST, SQ) render_pool_kernel<ST, SQ, 0>, render_pool_kernel<ST, SQ, 1>, render_pool_kernel<ST, SQ, 2>, render_pool_kernel<ST, SQ, 3>
+  static const RenderFn pool_table[16] = {RT_POOL(false, false), RT_POOL(false, true), RT_POOL(true, false), RT_POOL(true, true)};
+#undef RT_POOL
+  // (the same scenes with the wave's paths in a pool and every phase run on a full wave: RT_OPT_POOL_SLOTS)
+  if (trav == TRAV_STACK && A.pool_slots > 0) fn = pool_table[(stats ? 8 : 0) + (d_sumsq ? 4 : 0) + ctx->general];
   size_t lds_bytes = trav == TRAV_FLAT ? (size_t)ctx->dev.n_dprims * 6 * sizeof(float4) : 0;
-  if (trav == TRAV_STACK) lds_bytes = (size_t)A.stack_lds * 128 * sizeof(unsigned);
+  if (trav == TRAV_STACK) lds_bytes = (size_t)A.stack_lds * 128 * sizeof(unsigned) + (size_t)RT_POOL_LDS_DWORDS(A.pool_slots) * sizeof(unsigned);
 
   // All launches of a context share its counter and slabs (and all no_alloc launches on a device share `scratch`):
   // a launch on another stream than the last one first waits for that one to finish.
@@ -3528,6 +4194,7 @@ int rt_destroy(rt_ctx* ctx) {
   if (ctx->d_stats) (void)hipFree(ctx->d_stats);
   if (ctx->d_queue) (void)hipFree(ctx->d_queue);
   if (ctx->d_stack_ovf) (void)hipFree(ctx->d_stack_ovf);
+  if (ctx->d_pool) (void)hipFree(ctx->d_pool);
   if (ctx->d_slabs) (void)hipFree(ctx->d_slabs);
   for (int k = 0; k < 6; ++k)
     if (ctx->d_stage[k]) (void)hipFree(ctx->d_stage[k]);

@@ -115,3 +115,32 @@ def test_tuning_options_are_clamped_and_cannot_hang_the_kernel(gpu):
             gpu.set_option(k, v)
     with pytest.raises(Exception):
         gpu.set_option(99, 1)
+
+
+def test_pool_kernel_traces_the_same_paths(gpu):
+    """RT_OPT_POOL_SLOTS: the kernel that keeps a wave's paths in a pool and runs each
+    phase of the loop on a full wave traces exactly the paths the default kernel
+    traces: the same event counts, the same image to the order of fp32 additions
+    (all materials, textures and media: the final scene; lens and sky: Book 1)."""
+    from raytracing_amd._lib import RT_OPT_POOL_SLOTS, RT_SKY_GRADIENT
+    cases = []
+    with Scene(0x5EED0000) as sc:
+        cam, world = scenes.final_scene(1.5)
+        sc.light_xz_rect(*scenes.FINAL_LIGHT_SHAPE)
+        cases.append((cam, sc.flatten(world), make_params(240, 160, 24, seed=4)))
+    with Scene(3) as sc:
+        cam, world = scenes.random_scene(1.5)
+        cases.append((cam, sc.flatten(world), make_params(150, 100, 16, seed=8, sky=RT_SKY_GRADIENT)))
+    cam, flat = _field_150()
+    cases.append((cam, flat, make_params(96, 64, 32, seed=2)))
+    for cam, flat, p in cases:
+        gpu.upload_scene(flat)
+        ref, ref2, st = gpu.render(cam, p, want_sumsq=True, want_stats=True)
+        try:
+            for slots in (64, 128, 200):
+                gpu.set_option(RT_OPT_POOL_SLOTS, slots)
+                s, s2, st2 = gpu.render(cam, p, want_sumsq=True, want_stats=True)
+                assert st2.as_dict().items() - {("kernel_ms", st2.kernel_ms)} == st.as_dict().items() - {("kernel_ms", st.kernel_ms)}, slots
+                assert np.allclose(s, ref, rtol=1e-5, atol=1e-4) and np.allclose(s2, ref2, rtol=1e-5, atol=1e-3), slots
+        finally:
+            gpu.set_option(RT_OPT_POOL_SLOTS, 0)
