@@ -75,13 +75,27 @@ typedef struct rt_prim {
  *   RT_OBJ_LIST  : prims[first .. first+count) as a HitableList (a Cuboid,
  *                  src/hitable.rs:380-424, is its 6 rects in source order);
  *   RT_OBJ_BVH   : the sub-tree rooted at nodes[first] (a BvhNode used as a
- *                  child hitable); its leaves must be prim leaves;
+ *                  child hitable).  Its leaves may be objects again, to any
+ *                  depth the traversal stack allows (64 entries; each level
+ *                  costs four plus its tree's own), which is how every other
+ *                  nesting the constructors allow is written:
+ *                  RotateY(Translate(x)) is a rotate-only object around a
+ *                  sub-tree of one leaf that holds the translate-only object
+ *                  around x; a HitableList of such things is a sub-tree with
+ *                  one leaf per item, in the list's order.  A node that stands
+ *                  for no BvhNode of the source carries an infinite box (the
+ *                  source makes no box test there);
  *   RT_OBJ_MEDIUM: ConstantMedium (src/hitable.rs:542-604, commented out in
  *                  the reference) whose boundary is prims[first..first+count)
- *                  under the same optional rotate/translate. */
+ *                  under the same optional rotate/translate;
+ *   RT_OBJ_MEDIUM_BVH: the same with the sub-tree rooted at nodes[first] as the
+ *                  boundary (a BvhNode, or any nesting as for RT_OBJ_BVH).
+ * A medium must be a leaf of the world tree itself (the kernels walk the media
+ * after the tree, in the world's frame). */
 #define RT_OBJ_LIST 0
 #define RT_OBJ_BVH 1
 #define RT_OBJ_MEDIUM 2
+#define RT_OBJ_MEDIUM_BVH 3
 #define RT_XFORM_ROTATE_Y 1
 #define RT_XFORM_TRANSLATE 2
 

@@ -373,8 +373,8 @@ template <class P> struct World {
   bool medium_hit(int obj_index, const rt_object& ob, const Ray<P>& r, R t_min, R t_max, const Sampler& smp,
                   int depth, HitRecord<R>& rec) const {
     if (!smp.enabled) return false;
-    rt_object boundary = ob;
-    boundary.kind = RT_OBJ_LIST;
+    rt_object boundary = ob;  // (the boundary is any hitable: primitives, or a sub-tree)
+    boundary.kind = ob.kind == RT_OBJ_MEDIUM_BVH ? RT_OBJ_BVH : RT_OBJ_LIST;
     HitRecord<R> rec1, rec2;
     if (!xform_hit(boundary, r, -real_max(), real_max(), smp, depth, rec1)) return false;
     R t_next = rec1.t + R(0.0001);
@@ -411,7 +411,7 @@ template <class P> struct World {
     const int ref = ~n.left;
     if (n.right > 0) return list_hit(ref, n.right, r, t_min, t_max, rec);
     const rt_object& ob = s->objects[ref];
-    if (ob.kind == RT_OBJ_MEDIUM) return medium_hit(ref, ob, r, t_min, t_max, smp, depth, rec);
+    if (ob.kind == RT_OBJ_MEDIUM || ob.kind == RT_OBJ_MEDIUM_BVH) return medium_hit(ref, ob, r, t_min, t_max, smp, depth, rec);
     return xform_hit(ob, r, t_min, t_max, smp, depth, rec);
   }
 

@@ -19,7 +19,7 @@ RT_ERR_NO_SCENE = -4
 RT_PRIM_SPHERE, RT_PRIM_XY_RECT, RT_PRIM_XZ_RECT, RT_PRIM_YZ_RECT = 0, 1, 2, 3
 RT_PRIM_TYPE_MASK = 0xFF
 RT_PRIM_FLIP = 0x100
-RT_OBJ_LIST, RT_OBJ_BVH, RT_OBJ_MEDIUM = 0, 1, 2
+RT_OBJ_LIST, RT_OBJ_BVH, RT_OBJ_MEDIUM, RT_OBJ_MEDIUM_BVH = 0, 1, 2, 3
 RT_XFORM_ROTATE_Y, RT_XFORM_TRANSLATE = 1, 2
 RT_MAT_LAMBERTIAN, RT_MAT_DIFFUSE_LIGHT, RT_MAT_METAL, RT_MAT_DIELECTRIC, RT_MAT_ISOTROPIC = 0, 1, 2, 3, 4
 RT_TEX_CONSTANT, RT_TEX_CHECKER, RT_TEX_NOISE = 0, 1, 2

@@ -91,6 +91,7 @@ struct ScanNode {
 #define DP_XFORM_SHIFT 4   // 2 bits: RT_XFORM_*
 #define DP_MAT_SHIFT 6     // 3 bits: RT_MAT_*
 #define DP_TEXTURED 0x200  // the colour must come from Texture::value (checker / noise)
+#define DP_CHAINED 0x400   // the primitive lies inside more than one object: see DevScene::prim_obj
 #define DP_INDEX_SHIFT 12  // material index
 struct DevPrim {
   int flags;
@@ -133,6 +134,16 @@ struct DevScene {
   const float4* box6_recs; // 5 float4 per record: the 18 floats of box6_test, padded
   const int* prim_rank;  // per primitive: depth-first rank of its leaf
   const rt_object* objects;
+  // Objects inside objects (RotateY(Translate(x)), an instanced sub-tree that holds instances ...): a primitive under
+  // more than one of them carries DP_CHAINED, and its hit is carried back to the world through the objects
+  // chain_objs[obj_chain[2 * o] .. + obj_chain[2 * o + 1]) (outermost first) of its innermost object o = prim_obj[prim].
+  int has_chains;
+  const int* prim_obj;
+  const int* obj_chain;
+  const int* chain_objs;
+  // ConstantMedia whose boundary is a sub-tree (RT_OBJ_MEDIUM_BVH): walked after the tree like the others, by their own code
+  const struct MediumBvh* media_bvh;
+  int n_media_bvh;
   const rt_node* ref_nodes;  // the node array as it was passed in (trace64_kernel walks it the reference's way)
   int n_ref_nodes;
   int stack_mode;
@@ -144,6 +155,18 @@ struct DevScene {
 };
 
 static_assert(sizeof(rt_prim) == 32 && sizeof(ScanNode) == 64, "record sizes the byte-offset loads assume");
+
+// A ConstantMedium whose boundary is a sub-tree: the box of the world-tree leaf that holds it (bvh.rs:198 tests it
+// before the medium is asked), the object, and what ConstantMedium::hit needs.
+struct MediumBvh {
+  float bmin[3], bmax[3];
+  int object;    // index into objects (its transform; its sub-tree's box node is objects[object].first)
+  float density;
+  int ordinal;   // selects the random-number stream (rt_object.medium_index)
+  int dprim;     // the DevPrim of its scattering point
+  int pad[2];
+};
+static_assert(sizeof(MediumBvh) == 48, "three 16-byte scalar loads");
 
 // The breadth-first node array as the stack traversal keeps it, 32 bytes per node:
 // the box (read for the root and for the root of an object's sub-tree) and, for a
@@ -175,6 +198,7 @@ static_assert(sizeof(BNode4) == 128, "one cache line");
 #define BN2_BOX6 0x10000000  // with BN2_LEAF: a list of six rects in Cuboid::new's order, the low bits are its record's index
 #define BN4_EMPTY (-2)
 #define RT_MAX_TREE_DEPTH 64  // rt_upload_scene refuses node trees deeper than this
+#define RT_MAX_NEST 8         // and objects nested deeper than this (an object in a sub-tree of an object ...)
 #define STACK_DEPTH 64  // deepest tree the stack traversal takes; the launch sizes the LDS stack to the scene's own depth
 #define STACK_RESTORE 0xffffffffu
 
@@ -1071,15 +1095,15 @@ __device__ __forceinline__ void trav_leaf(const DevScene& S, STK& stk, Trav& T, 
     return;
   }
   const rt_object ob = S.objects[ref];
-  if (ob.kind == RT_OBJ_MEDIUM) return;
-  // (objects are leaves of the world tree only, so the lane is in the world frame here: T.r is the world ray)
+  if (ob.kind >= RT_OBJ_MEDIUM) return;
+  // (T.r is the ray in the frame the lane is in: the world's, or an enclosing object's)
   const RayF q = to_object_frame<true>(T.r, ob.xform, ob.sin_theta, ob.cos_theta, ob.offset[0], ob.offset[1], ob.offset[2]);
   if (STATS) cnt.instance_ops++;
   if (ob.kind == RT_OBJ_LIST) {
     leaf_list_lane<STATS>(S, ob.first, ob.count, q, t_min, t_max, T.best, cnt);
   } else {
-    // the lane keeps one ray, the one of the frame it is in: the world ray goes on the stack (three entries: a
-    // component of the origin where a reference would be, of the direction where its key would be) under the marker
+    // the lane keeps one ray, the one of the frame it is in: the ray of the frame it leaves goes on the stack (three
+    // entries: a component of the origin where a reference would be, of the direction where its key would be) under the marker
     stk.put(T.sp, __float_as_uint(T.r.o.x), __float_as_uint(T.r.d.x));
     stk.put(T.sp + 1, __float_as_uint(T.r.o.y), __float_as_uint(T.r.d.y));
     stk.put(T.sp + 2, __float_as_uint(T.r.o.z), __float_as_uint(T.r.d.z));
@@ -1096,18 +1120,16 @@ __device__ __forceinline__ void trav_leaf(const DevScene& S, STK& stk, Trav& T, 
 // right one win an exact tie (bvh.rs:204-217); visiting in another order gives the same winner when a tie goes to
 // the leaf that comes later in depth-first order, so every primitive has the rank of its leaf in prim_rank[],
 // read only on a tie.
-template <bool STATS>
-__device__ __forceinline__ void trace_stack(const DevScene& S, unsigned* __restrict__ stk_lds, const RayF& w, float t_min, float t_max, Hit& best,
-                                            Counters& cnt) {
-  LaneStackT<false> stk;
-  stk.lds = (lds_u32*)stk_lds;
-  stk.n_lds = S.stack_lds;
-  stk.ovf = nullptr;
+// The walk of one tree for one lane, from its root's box test on: `root_ref` the root's reference, `box_node` the node
+// that holds the root's box.
+template <bool STATS, class STK>
+__device__ __forceinline__ void trace_tree(const DevScene& S, STK& stk, int root_ref, int box_node, const RayF& w, float t_min, float t_max, Hit& best,
+                                           Counters& cnt) {
   Trav T;
   T.r = w;
   T.sp = 0;
   T.best = best;
-  T.cur = trav_enter<STATS>(S, S.root_ref, 0, w, t_min, t_max, cnt);
+  T.cur = trav_enter<STATS>(S, root_ref, box_node, w, t_min, t_max, cnt);
   for (;;) {
     // down until this lane holds a list or instance leaf (lanes that have one wait for the rest of the wave,
     // so the leaf code runs once for many lanes instead of once per step)
@@ -1117,6 +1139,60 @@ __device__ __forceinline__ void trace_stack(const DevScene& S, unsigned* __restr
     trav_leaf<STATS>(S, stk, T, t_min, t_max, cnt);
   }
   best = T.best;
+}
+template <bool STATS>
+__device__ __forceinline__ void trace_stack(const DevScene& S, unsigned* __restrict__ stk_lds, const RayF& w, float t_min, float t_max, Hit& best,
+                                            Counters& cnt) {
+  LaneStackT<false> stk;
+  stk.lds = (lds_u32*)stk_lds;
+  stk.n_lds = S.stack_lds;
+  stk.ovf = nullptr;
+  trace_tree<STATS>(S, stk, S.root_ref, 0, w, t_min, t_max, best, cnt);
+}
+
+// ConstantMedium::hit (hitable.rs:560-598, commented out in the reference) for the media whose boundary is a sub-tree:
+// the two boundary searches are walks of that tree by the lane's own stack (free at this point: the lane's walk of the
+// world has ended), the rest is scan_range's K_MEDIUM code.  All 64 lanes take part; `act` marks the ones with a ray.
+template <bool STATS, class STK>
+__device__ __forceinline__ void media_bvh_pass(const DevScene& S, STK& stk, bool act, const RayF& r, float t_min, float t_max, const PathRng& rng,
+                                               Hit& best, Counters& cnt) {
+  const float big = 3.402823466e+38f;
+  for (int m = 0; m < S.n_media_bvh; ++m) {
+    const MediumBvh mb = S.media_bvh[m];
+    const rt_object ob = S.objects[mb.object];
+    if (STATS) cnt.node_tests += act;
+    const bool on = act & slab_box(mb.bmin[0], mb.bmin[1], mb.bmin[2], mb.bmax[0], mb.bmax[1], mb.bmax[2], r, ray_signs(r), t_min, t_max);
+    if (__ballot(on) == 0ull) continue;
+    const RayF q = to_object_frame<true, true>(r, ob.xform, ob.sin_theta, ob.cos_theta, ob.offset[0], ob.offset[1], ob.offset[2]);
+    if (STATS) cnt.instance_ops += on;
+    Hit b1, b2;
+    b1.t = big; b1.prim = -1;
+    b2.t = big; b2.prim = -1;
+    const int root = S.sub_root_ref[mb.object];
+    if (on) trace_tree<STATS>(S, stk, root, ob.first, q, -big, big, b1, cnt);
+    float t_next = b1.t + 0.0001f;
+    {
+      const int bits = __float_as_int(b1.t);
+      const float up = __int_as_float(bits >= 0 ? bits + 1 : (bits == (int)0x80000000 ? 1 : bits - 1));
+      t_next = t_next > b1.t ? t_next : up;
+    }
+    if (on & (b1.prim >= 0)) trace_tree<STATS>(S, stk, root, ob.first, q, t_next, big, b2, cnt);
+    float t1 = b1.t, t2 = b2.t;
+    t1 = t1 < t_min ? t_min : t1;
+    t2 = t2 > t_max ? t_max : t2;
+    bool ok = on & (b1.prim >= 0) & (b2.prim >= 0) & !(t1 >= t2);
+    if (__ballot(ok) != 0ull) {
+      t1 = t1 < 0.0f ? 0.0f : t1;
+      const float dlen = sqrtf(dot3(r.d, r.d));
+      const float inside = (t2 - t1) * dlen;
+      const U4 mw = philox4x32_10(rng.pixel, rng.sample, rng.depth, 4096u + (unsigned)mb.ordinal, rng.key0, rng.key1);
+      const float hit_distance = -(1.0f / mb.density) * __logf(u01(mw.x));
+      const float t = t1 + hit_distance / dlen;
+      ok &= (hit_distance < inside) & !(best.t < t);
+      best.t = ok ? t : best.t;
+      best.prim = ok ? mb.dprim : best.prim;
+    }
+  }
 }
 
 // Nearest hit of BvhNode::hit (bvh.rs:197-228).  Must be called by all 64 lanes.
@@ -1167,10 +1243,26 @@ struct Surface {
 // The HitRecord fields color() needs (hitable.rs:175-182, 62-67), carried back
 // to the world frame by RotateY::hit (hitable.rs:521-528) and Translate::hit
 // (hitable.rs:442).  `q` is the hit primitive's DevPrim.
-__device__ __forceinline__ Surface finalize_hit(const DevPrim& q, const RayF& w, float t, bool has_spheres) {
+// A primitive inside more than one object (DP_CHAINED; `prim` is its index) goes through its objects one by one,
+// outermost first on the way in and innermost first on the way back, as the nested hit() calls of the source do.
+__device__ __forceinline__ Surface finalize_hit(const DevScene& S, const DevPrim& q, int prim, const RayF& w, float t, bool has_spheres) {
   Surface s;
   const int xform = (q.flags >> DP_XFORM_SHIFT) & 3;
-  const RayF r = to_object_frame<false>(w, xform, q.sin_t, q.cos_t, q.off[0], q.off[1], q.off[2]);
+  RayF r = to_object_frame<false>(w, xform, q.sin_t, q.cos_t, q.off[0], q.off[1], q.off[2]);
+  const bool chained = S.has_chains != 0 && (q.flags & DP_CHAINED) != 0;
+  int ch_first = 0, ch_len = 0;
+  if (S.has_chains != 0 && __ballot(chained) != 0ull) {  // (wave-uniform: scenes without such nestings never come here)
+    if (chained) {
+      const int ob = S.prim_obj[prim];
+      ch_first = S.obj_chain[2 * ob];
+      ch_len = S.obj_chain[2 * ob + 1];
+      r = w;
+      for (int i = 0; i < ch_len; ++i) {
+        const rt_object o = S.objects[S.chain_objs[ch_first + i]];
+        r = to_object_frame<false>(r, o.xform, o.sin_theta, o.cos_theta, o.offset[0], o.offset[1], o.offset[2]);
+      }
+    }
+  }
   F3 p = f3(fmaf(t, r.d.x, r.o.x), fmaf(t, r.d.y, r.o.y), fmaf(t, r.d.z, r.o.z));
   const int type = q.flags & DP_TYPE_MASK;
   const float sgn = (q.flags & DP_FLIP) ? -1.0f : 1.0f;
@@ -1195,6 +1287,21 @@ __device__ __forceinline__ Surface finalize_hit(const DevPrim& q, const RayF& w,
   nrm.x = ro ? fmaf(q.cos_t, nl.x, q.sin_t * nl.z) : nl.x;
   nrm.z = ro ? fmaf(-q.sin_t, nl.x, q.cos_t * nl.z) : nl.z;
   p = sel3(tr, f3(p.x + q.off[0], p.y + q.off[1], p.z + q.off[2]), p);
+  if (S.has_chains != 0 && __ballot(chained) != 0ull) {
+    if (chained) {
+      for (int i = ch_len - 1; i >= 0; --i) {
+        const rt_object o = S.objects[S.chain_objs[ch_first + i]];
+        if (o.xform & RT_XFORM_ROTATE_Y) {
+          const F3 pl2 = p, nl2 = nrm;
+          p.x = fmaf(o.cos_theta, pl2.x, o.sin_theta * pl2.z);
+          p.z = fmaf(-o.sin_theta, pl2.x, o.cos_theta * pl2.z);
+          nrm.x = fmaf(o.cos_theta, nl2.x, o.sin_theta * nl2.z);
+          nrm.z = fmaf(-o.sin_theta, nl2.x, o.cos_theta * nl2.z);
+        }
+        if (o.xform & RT_XFORM_TRANSLATE) p = f3(p.x + o.offset[0], p.y + o.offset[1], p.z + o.offset[2]);
+      }
+    }
+  }
   s.p = p;
   s.normal = nrm;
   return s;
@@ -1226,7 +1333,7 @@ __global__ void __launch_bounds__(256) trace_kernel(DevScene S, const float* __r
         Surface s;
         s.p = f3(0, 0, 0);
         s.normal = f3(0, 0, 0);
-        if (h.prim >= 0) s = finalize_hit(S.dprims[h.prim], w, h.t, S.has_spheres != 0);
+        if (h.prim >= 0) s = finalize_hit(S, S.dprims[h.prim], h.prim, w, h.t, S.has_spheres != 0);
         if (normal) { normal[3 * idx] = s.normal.x; normal[3 * idx + 1] = s.normal.y; normal[3 * idx + 2] = s.normal.z; }
         if (p_out) { p_out[3 * idx] = s.p.x; p_out[3 * idx + 1] = s.p.y; p_out[3 * idx + 2] = s.p.z; }
       }
@@ -1327,11 +1434,15 @@ __device__ __forceinline__ bool list_hit64(const DevScene& S, int first, int cou
 
 // BvhNode::hit over the tree under `root` (bvh.rs:197-228), iteratively: the leaves are met left to right, every one is
 // tested against the same (t_min, t_max), and a leaf's hit replaces the one held unless that one is strictly nearer,
-// which is the source's `if left.t < right.t { left } else { right }` folded over the leaves.  OBJECTS: the world tree
-// (its leaves may be objects); false inside an object's own sub-tree (primitive leaves only).
-template <bool OBJECTS>
+// which is the source's `if left.t < right.t { left } else { right }` folded over the leaves.  LEVEL: how many objects
+// the tree lies inside (0: the world tree); an object's sub-tree is walked by the next level's copy of the function,
+// up to RT_MAX_NEST (rt_upload_scene refuses deeper nestings), so the recursion is unrolled at compile time.
+template <int LEVEL>
 __device__ bool tree_hit64(const DevScene& S, int root, const D3& o, const D3& d, double t_min, double t_max, Hit64& best);
+template <>
+__device__ bool tree_hit64<RT_MAX_NEST + 1>(const DevScene&, int, const D3&, const D3&, double, double, Hit64&) { return false; }
 
+template <int LEVEL>
 __device__ __forceinline__ bool object_hit64(const DevScene& S, const rt_object& ob, const D3& o, const D3& d, double t_min, double t_max, Hit64& rec) {
   // Translate::hit around RotateY::hit, hitable.rs:438-446, 508-532
   D3 lo = o, ld = d;
@@ -1346,7 +1457,7 @@ __device__ __forceinline__ bool object_hit64(const DevScene& S, const rt_object&
     ld.z = sin_t * pd.x + cos_t * pd.z;
   }
   bool hit;
-  if (ob.kind == RT_OBJ_BVH) hit = tree_hit64<false>(S, ob.first, lo, ld, t_min, t_max, rec);
+  if (ob.kind == RT_OBJ_BVH) hit = tree_hit64<LEVEL + 1>(S, ob.first, lo, ld, t_min, t_max, rec);
   else hit = list_hit64(S, ob.first, ob.count, lo, ld, t_min, t_max, rec);
   if (!hit) return false;
   if (ob.xform & RT_XFORM_ROTATE_Y) {
@@ -1360,7 +1471,7 @@ __device__ __forceinline__ bool object_hit64(const DevScene& S, const rt_object&
   return true;
 }
 
-template <bool OBJECTS>
+template <int LEVEL>
 __device__ bool tree_hit64(const DevScene& S, int root, const D3& o, const D3& d, double t_min, double t_max, Hit64& best) {
   int stack[RT_MAX_TREE_DEPTH + 2];
   int sp = 0;
@@ -1381,10 +1492,10 @@ __device__ bool tree_hit64(const DevScene& S, int root, const D3& o, const D3& d
     if (n.right > 0) {
       hit = list_hit64(S, ref, n.right, o, d, t_min, t_max, rec);
     } else {
-      if (!OBJECTS) continue;
       const rt_object ob = S.objects[ref];
-      if (ob.kind == RT_OBJ_MEDIUM) continue;  // a deterministic query skips media, as rt_trace_closest does
-      hit = object_hit64(S, ob, o, d, t_min, t_max, rec);
+      if (ob.kind >= RT_OBJ_MEDIUM) continue;  // a deterministic query skips media, as rt_trace_closest does
+      if (LEVEL < RT_MAX_NEST) hit = object_hit64<LEVEL>(S, ob, o, d, t_min, t_max, rec);
+      else continue;
     }
     if (hit && (!any || !(best.t < rec.t))) {
       best = rec;
@@ -1406,7 +1517,7 @@ __global__ void __launch_bounds__(64) trace64_kernel(DevScene S, const double* _
     best.p = D3{0.0, 0.0, 0.0};
     best.n = D3{0.0, 0.0, 0.0};
     Hit64 rec;
-    if (S.n_ref_nodes > 0 && tree_hit64<true>(S, 0, ro, rd, t_min, t_max, rec)) best = rec;
+    if (S.n_ref_nodes > 0 && tree_hit64<0>(S, 0, ro, rd, t_min, t_max, rec)) best = rec;
     prim_id[i] = best.prim;
     t_out[i] = best.t;
     if (normal) { normal[3 * i] = best.n.x; normal[3 * i + 1] = best.n.y; normal[3 * i + 2] = best.n.z; }
@@ -1670,7 +1781,7 @@ __device__ __forceinline__ Shaded shade_vertex(const DevScene& S, const float4* 
     __builtin_memcpy((char*)&q + 32, &q2, 16);
     __builtin_memcpy((char*)&q + 48, &q3, 16);
   }
-  const Surface sf = finalize_hit(q, ray, h.t, S.has_spheres != 0);
+  const Surface sf = finalize_hit(S, q, hit ? h.prim : 0, ray, h.t, S.has_spheres != 0);
   const int mat_type = (q.flags >> DP_MAT_SHIFT) & 7;
   F3 color = f3(q.color[0], q.color[1], q.color[2]);
   if (STATS) cnt.hits += hit;
@@ -2325,6 +2436,10 @@ __global__ void __launch_bounds__(64, GENERAL < 2 ? RT_STACK_WAVES : 5) render_s
       if (GENERAL != 0 && S.n_scan > 0) {
         const PathRng rng = {pixel_id, sample, (unsigned)depth, key0, key1};
         scan_range<STATS, true, true, 0>(S, 0, S.n_scan, act, RT_WORLD_RAY(), a_t_min, INFINITY, rng, T.best, cnt);
+      }
+      if (GENERAL != 0 && S.n_media_bvh > 0) {
+        const PathRng rng = {pixel_id, sample, (unsigned)depth, key0, key1};
+        media_bvh_pass<STATS>(S, stk, act, RT_WORLD_RAY(), a_t_min, INFINITY, rng, T.best, cnt);
       }
       RT_STAMP(1);  // media
       const U4 w = philox4x32_10(pixel_id, sample, (unsigned)depth, 0u, key0, key1);
@@ -3192,6 +3307,10 @@ struct rt_ctx {
   void* d_box6_recs;
   void* d_prim_rank;
   void* d_objects;
+  void* d_prim_obj;
+  void* d_obj_chain;
+  void* d_chain_objs;
+  void* d_media_bvh;
   void* d_materials;
   void* d_textures;
   void* d_perlins;
@@ -3256,7 +3375,7 @@ int hip_fail(hipError_t e, const char* what) {
   } while (0)
 
 void free_scene(rt_ctx* ctx) {
-  void** ptrs[] = {&ctx->d_scan, &ctx->d_prims, &ctx->d_ref_nodes, &ctx->d_dprims, &ctx->d_leaf_box, &ctx->d_bnodes, &ctx->d_bnodes4, &ctx->d_sub_root_ref, &ctx->d_box6_index, &ctx->d_box6_recs, &ctx->d_prim_rank, &ctx->d_objects, &ctx->d_materials, &ctx->d_textures, &ctx->d_perlins, &ctx->d_lights};
+  void** ptrs[] = {&ctx->d_scan, &ctx->d_prims, &ctx->d_ref_nodes, &ctx->d_dprims, &ctx->d_leaf_box, &ctx->d_bnodes, &ctx->d_bnodes4, &ctx->d_sub_root_ref, &ctx->d_box6_index, &ctx->d_box6_recs, &ctx->d_prim_rank, &ctx->d_objects, &ctx->d_prim_obj, &ctx->d_obj_chain, &ctx->d_chain_objs, &ctx->d_media_bvh, &ctx->d_materials, &ctx->d_textures, &ctx->d_perlins, &ctx->d_lights};
   for (size_t i = 0; i < sizeof(ptrs) / sizeof(ptrs[0]); ++i) {
     if (*ptrs[i]) (void)hipFree(*ptrs[i]);
     *ptrs[i] = nullptr;
@@ -3328,8 +3447,13 @@ int validate_scene(const rt_scene* s) {
         if (o.medium_index < 0 || o.medium_index >= s->n_objects) return rt::set_error(RT_ERR_INVALID, "medium ordinal out of range");
         if (!(o.density > 0.0f)) return rt::set_error(RT_ERR_INVALID, "medium density must be positive");
       }
-    } else if (o.kind == RT_OBJ_BVH) {
+    } else if (o.kind == RT_OBJ_BVH || o.kind == RT_OBJ_MEDIUM_BVH) {
       if (o.first <= 0 || o.first >= s->n_nodes) return rt::set_error(RT_ERR_INVALID, "object sub-tree root out of range");
+      if (o.kind == RT_OBJ_MEDIUM_BVH) {
+        if (o.material < 0 || o.material >= s->n_materials) return rt::set_error(RT_ERR_INVALID, "medium material index out of range");
+        if (o.medium_index < 0 || o.medium_index >= s->n_objects) return rt::set_error(RT_ERR_INVALID, "medium ordinal out of range");
+        if (!(o.density > 0.0f)) return rt::set_error(RT_ERR_INVALID, "medium density must be positive");
+      }
     } else {
       return rt::set_error(RT_ERR_INVALID, "unknown object kind");
     }
@@ -3357,6 +3481,53 @@ int count_leaves(const rt_scene* s, int idx, int depth, std::vector<int>* memo) 
   return leaves;
 }
 
+// Which object every primitive and every object lies in, with the structural checks of every tree of the scene (the
+// world's and every object's sub-tree: indices in range, no node or object reached twice, bounded depth and nesting)
+// done on the way, so that everything after it can follow the indices without looking.
+struct FrameWalk {
+  const rt_scene* s;
+  std::vector<int>* leaves;     // count_leaves' memo, shared by all trees (a node reached from two places is an error)
+  std::vector<int> prim_obj;    // per primitive: the innermost object it lies in, -1 for none
+  std::vector<int> obj_parent;  // per object: the object it lies in, -1 for the world
+  std::vector<char> obj_seen;
+  bool nested;                  // an object inside an object, or a medium bounded by a sub-tree: only the stack traversal takes those
+  int walk_tree(int root, int parent_obj, int nest) {
+    if (nest > RT_MAX_NEST) return rt::set_error(RT_ERR_UNSUPPORTED, "objects nested more than 8 deep");
+    const int rc = count_leaves(s, root, 0, leaves);
+    if (rc < 0) return rc;
+    return visit(root, parent_obj, nest);
+  }
+  int visit(int idx, int parent_obj, int nest) {
+    const rt_node& n = s->nodes[idx];
+    if (n.left >= 0) {
+      const int rc = visit(n.left, parent_obj, nest);
+      if (rc != RT_OK) return rc;
+      return visit(n.right, parent_obj, nest);
+    }
+    const int ref = ~n.left;
+    if (n.right > 0) {
+      if (ref < 0 || ref > s->n_prims - n.right) return rt::set_error(RT_ERR_INVALID, "leaf primitive range out of bounds");
+      for (int k = ref; k < ref + n.right; ++k) prim_obj[(size_t)k] = parent_obj;
+      return RT_OK;
+    }
+    if (n.right < 0) return rt::set_error(RT_ERR_INVALID, "leaf with negative count");
+    if (ref < 0 || ref >= s->n_objects) return rt::set_error(RT_ERR_INVALID, "leaf object index out of range");
+    if (obj_seen[(size_t)ref]) return rt::set_error(RT_ERR_INVALID, "an object is the leaf of two nodes");
+    obj_seen[(size_t)ref] = 1;
+    obj_parent[(size_t)ref] = parent_obj;
+    const rt_object& ob = s->objects[ref];
+    if (parent_obj >= 0) nested = true;
+    if (ob.kind >= RT_OBJ_MEDIUM && parent_obj >= 0)
+      return rt::set_error(RT_ERR_UNSUPPORTED, "a ConstantMedium inside another object is not supported: media must be leaves of the world tree");
+    if (ob.kind == RT_OBJ_LIST || ob.kind == RT_OBJ_MEDIUM) {
+      for (int k = ob.first; k < ob.first + ob.count; ++k) prim_obj[(size_t)k] = ref;
+      return RT_OK;
+    }
+    if (ob.kind == RT_OBJ_MEDIUM_BVH) nested = true;
+    return walk_tree(ob.first, ref, nest + 1);
+  }
+};
+
 // Sub-trees with at most this many leaves are stored as their leaves alone.  A
 // leaf's box lies inside every ancestor's box and the slab arithmetic is
 // monotonic in the box bounds, so a ray that passes the leaf's Aabb::hit passes
@@ -3376,6 +3547,7 @@ struct ScanBuilder {
   std::vector<float> y_top;     // per node, see compute_y_top
   std::vector<int> media;  // object index of each ConstantMedium, in scan order
   bool any_interior;
+  bool incomplete;  // the array leaves something out that only the stack traversal takes (objects inside objects, media bounded by a sub-tree)
   void set_leaf_box(int prim, const rt_node& n) {
     float* b = &leaf_box[(size_t)prim * 8];
     for (int c = 0; c < 3; ++c) { b[c] = n.bmin[c]; b[4 + c] = n.bmax[c]; }
@@ -3452,7 +3624,7 @@ float compute_y_top(const rt_scene* s, int idx, int depth, std::vector<float>* y
   } else if (~n.left < s->n_objects) {
     const rt_object& ob = s->objects[~n.left];
     const double lift = (ob.xform & RT_XFORM_TRANSLATE) ? (double)ob.offset[1] : 0.0;
-    const double inner = ob.kind == RT_OBJ_BVH ? (double)compute_y_top(s, ob.first, depth + 1, y_top) : geometry_top(s, ob.first, ob.count);
+    const double inner = (ob.kind == RT_OBJ_BVH || ob.kind == RT_OBJ_MEDIUM_BVH) ? (double)compute_y_top(s, ob.first, depth + 1, y_top) : geometry_top(s, ob.first, ob.count);
     top = std::max(top, round_up(inner + lift));
   }
   (*y_top)[(size_t)idx] = top;
@@ -3517,9 +3689,13 @@ int build_scan(ScanBuilder* B, int idx, bool in_sub, bool collapsed, bool tree_r
     return RT_OK;
   }
   if (n.right < 0) return rt::set_error(RT_ERR_INVALID, "leaf with negative count");
-  if (in_sub) return rt::set_error(RT_ERR_UNSUPPORTED, "objects inside an object's sub-tree are not supported");
   if (ref < 0 || ref >= s->n_objects) return rt::set_error(RT_ERR_INVALID, "leaf object index out of range");
   const rt_object& ob = s->objects[ref];
+  if (in_sub) {
+    // an object inside an object: the scan does not take it (the stack traversal does)
+    B->incomplete = true;
+    return RT_OK;
+  }
   sn.f[0] = ob.sin_theta; sn.f[1] = ob.cos_theta;
   sn.f[2] = ob.offset[0]; sn.f[3] = ob.offset[1]; sn.f[4] = ob.offset[2];
   const size_t at = B->out.size();
@@ -3549,17 +3725,19 @@ int build_scan(ScanBuilder* B, int idx, bool in_sub, bool collapsed, bool tree_r
     }
     return RT_OK;
   }
+  if (ob.kind == RT_OBJ_MEDIUM_BVH) {
+    // a medium bounded by a sub-tree: no scan node (media_bvh_pass walks it); its scattering record comes after the primitives like the others'
+    B->incomplete = true;
+    B->leaf_box.resize(((size_t)s->n_prims + B->media.size() + 1) * 8, 0.0f);
+    B->set_leaf_box(s->n_prims + (int)B->media.size(), n);
+    B->media.push_back(ref);
+    return RT_OK;
+  }
   // RT_OBJ_BVH: the sub-tree follows inline, in the object's frame.
   sn.kind = K_OBJ_BVH;
   sn.b = ob.xform << 24;
   B->out.push_back(sn);
   B->any_interior = true;
-  if (B->leaves[ob.first] == 0) {
-    const int rc = count_leaves(s, ob.first, 0, &B->leaves);
-    if (rc < 0) return rc;
-  } else {
-    return rt::set_error(RT_ERR_INVALID, "object sub-tree is shared with another node");
-  }
   const int rc = build_scan(B, ob.first, true, false, true, ref);
   if (rc != RT_OK) return rc;
   B->out[at].skip = (int)B->out.size();
@@ -3573,7 +3751,7 @@ int tree_depth(const rt_scene* s, int idx) {
     const int a = tree_depth(s, n.left), b = tree_depth(s, n.right);
     return 1 + (a > b ? a : b);
   }
-  if (n.right == 0 && s->objects[~n.left].kind == RT_OBJ_BVH) return 2 + tree_depth(s, s->objects[~n.left].first);
+  if (n.right == 0 && (s->objects[~n.left].kind == RT_OBJ_BVH || s->objects[~n.left].kind == RT_OBJ_MEDIUM_BVH)) return 2 + tree_depth(s, s->objects[~n.left].first);
   return 1;
 }
 
@@ -3594,11 +3772,12 @@ int build_bnodes(const rt_scene* s, int idx, std::vector<BNode>* out, std::vecto
   const int ref = ~n.left;
   if (n.right > 0) {
     for (int k = ref; k < ref + n.right; ++k) (*prim_rank)[(size_t)k] = *rank;
-  } else if (s->objects[ref].kind != RT_OBJ_BVH) {
+  } else if (s->objects[ref].kind == RT_OBJ_LIST || s->objects[ref].kind == RT_OBJ_MEDIUM) {
     for (int k = s->objects[ref].first; k < s->objects[ref].first + s->objects[ref].count; ++k) (*prim_rank)[(size_t)k] = *rank;
   }
   ++*rank;
-  if (n.right == 0 && s->objects[ref].kind == RT_OBJ_BVH) return build_bnodes(s, s->objects[ref].first, out, prim_rank, rank);
+  if (n.right == 0 && (s->objects[ref].kind == RT_OBJ_BVH || s->objects[ref].kind == RT_OBJ_MEDIUM_BVH))
+    return build_bnodes(s, s->objects[ref].first, out, prim_rank, rank);
   return RT_OK;
 }
 
@@ -3633,7 +3812,7 @@ struct TreeBuilder {
     const rt_node& n = s->nodes[idx];
     if (n.left < 0) {
       if (n.right == 0 && s->objects[~n.left].kind == RT_OBJ_BVH && (s->objects[~n.left].xform & 3) == 0) collect(s->objects[~n.left].first, out, media);
-      else if (media || !(n.right == 0 && s->objects[~n.left].kind == RT_OBJ_MEDIUM)) out->push_back(idx);
+      else if (media || !(n.right == 0 && s->objects[~n.left].kind >= RT_OBJ_MEDIUM)) out->push_back(idx);
       return;
     }
     collect(n.left, out, media);
@@ -3952,7 +4131,8 @@ int launch_render(rt_ctx* ctx, const rt_camera* cam, const rt_render_params* p, 
   // scenes with media or the older materials have the heavier shading phase: it is run for fuller waves
   A.ready_lanes = ctx->opt[RT_OPT_READY_LANES] > 0 ? ctx->opt[RT_OPT_READY_LANES] : (ctx->general != 0 ? 56 : RT_READY_LANES);
   A.hold_lanes = ctx->opt[RT_OPT_HOLD_LANES];
-  A.pool_slots = trav == TRAV_STACK ? ctx->opt[RT_OPT_POOL_SLOTS] : 0;
+  // (a medium bounded by a sub-tree is walked with the lane's own stack, which the pool kernel's lanes have in use while a batch is shaded)
+  A.pool_slots = (trav == TRAV_STACK && ctx->dev.n_media_bvh == 0) ? ctx->opt[RT_OPT_POOL_SLOTS] : 0;
   A.refill_lanes = ctx->opt[RT_OPT_REFILL_LANES];
   A.shade_batch = ctx->opt[RT_OPT_SHADE_BATCH];
   A.tex_batch = ctx->opt[RT_OPT_TEX_BATCH];
@@ -4218,7 +4398,15 @@ int rt_upload_scene_timed(rt_ctx* ctx, const rt_scene* s, double* upload_ms) {
   B.prim_obj.assign((size_t)s->n_prims, -1);
   B.leaf_box.assign((size_t)s->n_prims * 8, 0.0f);
   B.any_interior = false;
-  rc = count_leaves(s, 0, 0, &B.leaves);
+  B.incomplete = false;
+  FrameWalk FW;
+  FW.s = s;
+  FW.leaves = &B.leaves;
+  FW.prim_obj.assign((size_t)s->n_prims, -1);
+  FW.obj_parent.assign((size_t)s->n_objects, -1);
+  FW.obj_seen.assign((size_t)s->n_objects, 0);
+  FW.nested = false;
+  rc = FW.walk_tree(0, -1, 0);
   if (rc < 0) return rc;
   B.y_top.assign((size_t)s->n_nodes, 0.0f);
   (void)compute_y_top(s, 0, 0, &B.y_top);
@@ -4227,7 +4415,8 @@ int rt_upload_scene_timed(rt_ctx* ctx, const rt_scene* s, double* upload_ms) {
   // More than a treelet's worth of leaves: per-lane stack traversal over the
   // breadth-first nodes; the scan array then keeps only the ConstantMedium nodes.
   const int depth = tree_depth(s, 0);
-  const bool want_stack = B.any_interior && depth <= STACK_DEPTH - 2;
+  const bool nested = FW.nested || B.incomplete;
+  const bool want_stack = (B.any_interior || nested) && depth <= STACK_DEPTH - 2;
   // the four-wide entries of the interior nodes, and the six-rect records of the list leaves
   TreeBuilder TB;
   TB.s = s;
@@ -4262,18 +4451,31 @@ int rt_upload_scene_timed(rt_ctx* ctx, const rt_scene* s, double* upload_ms) {
       if (s->objects[i].kind == RT_OBJ_LIST) note_box6(s->objects[i].first, s->objects[i].count);
     if (box6_recs.size() / 20 > (size_t)BN_INDEX_MASK) return rt::set_error(RT_ERR_UNSUPPORTED, "too many cuboids");
     W.box6_index = &box6_index;
-    root_ref = W.ref_of(TB.build_under(0), &stack_need);
+    // the world's tree, and the tree of every medium that is bounded by one (walked on its own, after the world's)
+    auto build_all = [&]() {
+      root_ref = W.ref_of(TB.build_under(0), &stack_need);
+      for (int i = 0; i < s->n_objects; ++i) {
+        if (s->objects[i].kind != RT_OBJ_MEDIUM_BVH) continue;
+        int sub = 0;
+        W.sub_root_ref[(size_t)i] = W.ref_of(TB.build_under(s->objects[i].first), &sub);
+        if (sub > stack_need) stack_need = sub;
+      }
+    };
+    build_all();
     if (stack_need + 2 > RT_STACK_MAX) {
       // the heuristic's tree is too deep for a lane's stack: the balanced one over the same leaves
       TB.nodes.clear();
       TB.halve_only = true;
       W.out.clear();
-      root_ref = W.ref_of(TB.build_under(0), &stack_need);
+      build_all();
     }
     if (W.out.size() > (size_t)BN_INDEX_MASK) return rt::set_error(RT_ERR_UNSUPPORTED, "too many nodes");
   }
   // a tree whose walk could need more stack than a lane has (LDS part + private part) takes the scan
   const bool stack_mode = want_stack && stack_need + 2 <= RT_STACK_MAX;
+  if (nested && !stack_mode)
+    return rt::set_error(RT_ERR_UNSUPPORTED, "objects inside objects (or a medium bounded by a sub-tree) need the per-lane stack traversal, and this scene's "
+                                             "trees are deeper than its stack of 64 entries allows");
   std::vector<BNode> bnodes;
   std::vector<int> prim_rank((size_t)s->n_prims, 0);
   std::vector<ScanNode> media_scan;
@@ -4282,6 +4484,7 @@ int rt_upload_scene_timed(rt_ctx* ctx, const rt_scene* s, double* upload_ms) {
     int rank = 0;
     rc = build_bnodes(s, 0, &bnodes, &prim_rank, &rank);
     if (rc != RT_OK) return rc;
+    // (a medium is no leaf of the device's world tree, so build_bnodes, which follows the given one, has met every medium's sub-tree too)
     for (size_t i = 0; i < B.out.size();) {
       const int slots = B.out[i].kind == K_INTERIOR ? 1 : B.out[i].skip - (int)i;
       if (B.out[i].kind == K_MEDIUM) {
@@ -4301,7 +4504,7 @@ int rt_upload_scene_timed(rt_ctx* ctx, const rt_scene* s, double* upload_ms) {
   if ((rc = upload(&ctx->d_ref_nodes, s->nodes, (size_t)s->n_nodes)) != RT_OK) return rc;
   // One DevPrim per primitive: geometry + the frame it lives in + its material.
   std::vector<DevPrim> dprims((size_t)s->n_prims + B.media.size());
-  int mat_mask = 0, textured = 0;
+  int mat_mask = 0, textured = 0, has_chains = 0;
   for (size_t i = 0; i < dprims.size(); ++i) {
     const bool is_medium = i >= (size_t)s->n_prims;
     rt_prim q;
@@ -4317,15 +4520,21 @@ int rt_upload_scene_timed(rt_ctx* ctx, const rt_scene* s, double* upload_ms) {
     DevPrim& d = dprims[i];
     std::memset(&d, 0, sizeof(d));
     d.cos_t = 1.0f;
-    int xform = 0;
-    if (!is_medium && B.prim_obj[i] >= 0) {
-      const rt_object& ob = s->objects[B.prim_obj[i]];
-      xform = ob.xform & 3;
-      d.sin_t = ob.sin_theta; d.cos_t = ob.cos_theta;
-      d.off[0] = ob.offset[0]; d.off[1] = ob.offset[1]; d.off[2] = ob.offset[2];
+    int xform = 0, chained = 0;
+    if (!is_medium && FW.prim_obj[i] >= 0) {
+      const int po = FW.prim_obj[i];
+      if (FW.obj_parent[(size_t)po] >= 0) {
+        chained = DP_CHAINED;  // inside more than one object: finalize_hit goes through them one by one
+        has_chains = 1;
+      } else {
+        const rt_object& ob = s->objects[po];
+        xform = ob.xform & 3;
+        d.sin_t = ob.sin_theta; d.cos_t = ob.cos_theta;
+        d.off[0] = ob.offset[0]; d.off[1] = ob.offset[1]; d.off[2] = ob.offset[2];
+      }
     }
     d.flags = (q.type & DP_TYPE_MASK) | ((q.type & RT_PRIM_FLIP) ? DP_FLIP : 0) | (xform << DP_XFORM_SHIFT) |
-              (m.type << DP_MAT_SHIFT) | (q.material << DP_INDEX_SHIFT);
+              (m.type << DP_MAT_SHIFT) | (q.material << DP_INDEX_SHIFT) | chained;
     for (int k = 0; k < 5; ++k) d.f[k] = q.f[k];
     if (m.type == RT_MAT_METAL) {
       for (int k = 0; k < 3; ++k) d.color[k] = m.albedo[k];
@@ -4338,6 +4547,35 @@ int rt_upload_scene_timed(rt_ctx* ctx, const rt_scene* s, double* upload_ms) {
     d.ref_idx = m.ref_idx;
   }
   if ((rc = upload(&ctx->d_dprims, dprims.data(), dprims.size())) != RT_OK) return rc;
+  // the objects every object lies in, outermost first and itself last, for the primitives inside more than one
+  std::vector<int> obj_chain((size_t)s->n_objects * 2, 0), chain_objs;
+  if (has_chains) {
+    for (int o = 0; o < s->n_objects; ++o) {
+      std::vector<int> up;
+      for (int a = o; a >= 0; a = FW.obj_parent[(size_t)a]) up.push_back(a);
+      obj_chain[2 * (size_t)o] = (int)chain_objs.size();
+      obj_chain[2 * (size_t)o + 1] = (int)up.size();
+      chain_objs.insert(chain_objs.end(), up.rbegin(), up.rend());
+    }
+  }
+  std::vector<MediumBvh> media_bvh;
+  for (size_t k = 0; k < B.media.size(); ++k) {
+    const rt_object& ob = s->objects[B.media[k]];
+    if (ob.kind != RT_OBJ_MEDIUM_BVH) continue;
+    MediumBvh mb;
+    std::memset(&mb, 0, sizeof(mb));
+    const float* box = &B.leaf_box[((size_t)s->n_prims + k) * 8];
+    for (int c = 0; c < 3; ++c) { mb.bmin[c] = box[c]; mb.bmax[c] = box[4 + c]; }
+    mb.object = B.media[k];
+    mb.density = ob.density;
+    mb.ordinal = ob.medium_index;
+    mb.dprim = s->n_prims + (int)k;
+    media_bvh.push_back(mb);
+  }
+  if ((rc = upload(&ctx->d_prim_obj, FW.prim_obj.data(), FW.prim_obj.size())) != RT_OK) return rc;
+  if ((rc = upload(&ctx->d_obj_chain, obj_chain.data(), obj_chain.size())) != RT_OK) return rc;
+  if ((rc = upload(&ctx->d_chain_objs, chain_objs.data(), chain_objs.size())) != RT_OK) return rc;
+  if ((rc = upload(&ctx->d_media_bvh, media_bvh.data(), media_bvh.size())) != RT_OK) return rc;
   B.leaf_box.resize(dprims.size() * 8, 0.0f);
   if ((rc = upload(&ctx->d_leaf_box, B.leaf_box.data(), B.leaf_box.size())) != RT_OK) return rc;
   if ((rc = upload(&ctx->d_bnodes, bnodes.data(), bnodes.size())) != RT_OK) return rc;
@@ -4368,6 +4606,12 @@ int rt_upload_scene_timed(rt_ctx* ctx, const rt_scene* s, double* upload_ms) {
   d.box6_recs = (const float4*)ctx->d_box6_recs;
   d.prim_rank = (const int*)ctx->d_prim_rank;
   d.objects = (const rt_object*)ctx->d_objects;
+  d.has_chains = has_chains;
+  d.prim_obj = (const int*)ctx->d_prim_obj;
+  d.obj_chain = (const int*)ctx->d_obj_chain;
+  d.chain_objs = (const int*)ctx->d_chain_objs;
+  d.media_bvh = (const MediumBvh*)ctx->d_media_bvh;
+  d.n_media_bvh = (int)media_bvh.size();
   d.stack_mode = stack_mode ? 1 : 0;
   d.stack_depth = stack_mode ? stack_need + 2 : 0;  // what the deepest walk can have in use, and a margin
   d.stack_lds = d.stack_depth;  // (the trace kernel's; the render kernel's LDS part is set per launch)

@@ -241,7 +241,8 @@ struct Flattener {
   int n_media;
   std::vector<std::pair<int, const BvhNode*> > pending;  // object index -> sub-tree to emit
 
-  explicit Flattener(FlatScene* o) : out(o), n_media(0) {}
+  int nesting;
+  explicit Flattener(FlatScene* o) : out(o), n_media(0), nesting(0) {}
 
   void push_rect(const Rect* r, bool flip) {
     rt_prim p;
@@ -303,8 +304,16 @@ struct Flattener {
     }
   }
 
-  // Fills the leaf fields of `node` for the hitable a BvhNode leaf holds.
-  void emit_leaf(const Hitable* h, bool allow_objects, rt_node* node) {
+  // Fills the leaf fields of `node` for the hitable a BvhNode leaf holds.  Anything that is not plain primitives
+  // becomes an object: [ConstantMedium(] [Translate(] [RotateY(] inner, where inner is primitives (RT_OBJ_LIST /
+  // RT_OBJ_MEDIUM), a BvhNode (RT_OBJ_BVH / RT_OBJ_MEDIUM_BVH: its tree follows later) or anything else the
+  // constructors allow (hitable.rs:433,465 take any Box<dyn Hitable>): a further Translate or RotateY in any order, a
+  // HitableList holding such things.  That last case becomes a sub-tree too, made here: one leaf per item, in the list's
+  // order, every box infinite (no such box test exists in the reference: Translate::hit hands the ray straight to its
+  // child), and each leaf an object of its own, so `RotateY(Translate(x))` is an object in an object.
+  // `top_level`: the hitable is an item of the world itself.  A ConstantMedium must be one: the kernels walk the media
+  // after the tree, in the world's frame.
+  void emit_leaf(const Hitable* h, bool top_level, rt_node* node) {
     if (is_simple(h)) {
       const int first = (int)out->prims.size();
       emit_simple(h);
@@ -312,8 +321,6 @@ struct Flattener {
       node->right = (int)out->prims.size() - first;
       return;
     }
-    if (!allow_objects)
-      throw SceneError(RT_ERR_UNSUPPORTED, "a BvhNode used as a child hitable may hold only spheres, rects, cuboids and lists of those");
     rt_object ob;
     std::memset(&ob, 0, sizeof(ob));
     ob.cos_theta = 1.0f;
@@ -322,6 +329,8 @@ struct Flattener {
     const Hitable* cur = h;
     bool medium = false;
     if (cur->kind() == Hitable::CONSTANT_MEDIUM) {
+      if (!top_level)
+        throw SceneError(RT_ERR_UNSUPPORTED, "a ConstantMedium must be an item of the world's list: inside a Translate, a RotateY, a HitableList or a BvhNode it is not supported");
       const ConstantMedium* m = static_cast<const ConstantMedium*>(cur);
       medium = true;
       ob.density = (float)m->density;
@@ -342,23 +351,56 @@ struct Flattener {
       ob.cos_theta = (float)r->cos_theta;
       cur = r->hitable.get();
     }
+    // (the object takes its place in the array before its inside is emitted: the inside may add objects of its own)
     const int obj_index = (int)out->objects.size();
+    out->objects.push_back(ob);
     if (is_simple(cur)) {
       ob.kind = medium ? RT_OBJ_MEDIUM : RT_OBJ_LIST;
       ob.first = (int)out->prims.size();
       emit_simple(cur);
       ob.count = (int)out->prims.size() - ob.first;
-    } else if (cur->kind() == Hitable::BVH_NODE && !medium) {
-      ob.kind = RT_OBJ_BVH;
+    } else if (cur->kind() == Hitable::BVH_NODE) {
+      ob.kind = medium ? RT_OBJ_MEDIUM_BVH : RT_OBJ_BVH;
       ob.first = -1;  // patched when the sub-tree is emitted
       pending.push_back(std::make_pair(obj_index, static_cast<const BvhNode*>(cur)));
     } else {
-      throw SceneError(RT_ERR_UNSUPPORTED,
-                       "unsupported nesting: expected [ConstantMedium(] [Translate(] [RotateY(] primitives | Cuboid | HitableList of those | BvhNode");
+      if (++nesting > 64) throw SceneError(RT_ERR_UNSUPPORTED, "hitables nested more than 64 deep");
+      ob.kind = medium ? RT_OBJ_MEDIUM_BVH : RT_OBJ_BVH;
+      ob.first = emit_items(cur);
+      --nesting;
     }
-    out->objects.push_back(ob);
+    out->objects[(size_t)obj_index] = ob;
     node->left = ~obj_index;
     node->right = 0;
+  }
+
+  // A tree over the items of a HitableList in the list's order (or over the one hitable), every box infinite; returns its root.
+  int emit_items(const Hitable* h) {
+    std::vector<const Hitable*> items;
+    if (h->kind() == Hitable::HITABLE_LIST) {
+      const HitableList* l = static_cast<const HitableList*>(h);
+      for (size_t i = 0; i < l->list.size(); ++i) items.push_back(l->list[i].get());
+      if (items.empty()) throw SceneError(RT_ERR_INVALID, "an empty HitableList inside another hitable");
+    } else {
+      items.push_back(h);
+    }
+    return emit_item_range(items, 0, items.size());
+  }
+  int emit_item_range(const std::vector<const Hitable*>& items, size_t begin, size_t end) {
+    const int at = (int)out->nodes.size();
+    out->nodes.push_back(rt_node());
+    rt_node node;
+    std::memset(&node, 0, sizeof(node));
+    for (int c = 0; c < 3; ++c) { node.bmin[c] = -INFINITY; node.bmax[c] = INFINITY; }
+    if (end - begin == 1) {
+      emit_leaf(items[begin], false, &node);
+    } else {
+      const size_t mid = begin + (end - begin) / 2;
+      node.left = emit_item_range(items, begin, mid);
+      node.right = emit_item_range(items, mid, end);
+    }
+    out->nodes[(size_t)at] = node;
+    return at;
   }
 
   // The largest float not above v / the smallest not below v.
@@ -374,7 +416,7 @@ struct Flattener {
   }
 
   // Breadth-first emission of one tree; returns the index of its root.
-  int emit_tree(const BvhNode* root, bool allow_objects) {
+  int emit_tree(const BvhNode* root, bool top_level) {
     std::deque<std::pair<const BvhNode*, int> > queue;
     const int root_index = (int)out->nodes.size();
     out->nodes.push_back(rt_node());
@@ -390,7 +432,7 @@ struct Flattener {
       node.bmin[0] = float_below(n->boxy.min.x); node.bmin[1] = float_below(n->boxy.min.y); node.bmin[2] = float_below(n->boxy.min.z);
       node.bmax[0] = float_above(n->boxy.max.x); node.bmax[1] = float_above(n->boxy.max.y); node.bmax[2] = float_above(n->boxy.max.z);
       if (n->contents) {
-        emit_leaf(n->contents.get(), allow_objects, &node);
+        emit_leaf(n->contents.get(), top_level, &node);
       } else {
         node.left = (int)out->nodes.size();
         node.right = node.left + 1;
@@ -412,14 +454,15 @@ void flatten_world(const HitableList& world, const Tables& tables, HostRng& rng,
   out->prims.clear();
   out->objects.clear();
   out->tables = tables;
-  // main.rs:85-90: a BvhNode over the items of world.list.  A top-level item
-  // that is itself a BvhNode becomes a leaf holding a sub-tree.
+  // main.rs:85-90: a BvhNode over the items of world.list.  An item that is itself a BvhNode (or holds one under
+  // Translate / RotateY) becomes a leaf holding a sub-tree; sub-trees may hold further ones.
   BvhNode top(world.list, rng);
   Flattener f(out);
   f.emit_tree(&top, true);
   for (size_t i = 0; i < f.pending.size(); ++i) {
+    const int at = f.pending[i].first;
     const int root = f.emit_tree(f.pending[i].second, false);
-    out->objects[f.pending[i].first].first = root;
+    out->objects[(size_t)at].first = root;
   }
 }
 

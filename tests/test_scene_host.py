@@ -134,12 +134,45 @@ def test_error_paths():
         assert e.value.code == _lib.RT_ERR_INVALID
         with pytest.raises(RtError):
             S.BvhNode.new([])
-        # nesting the flattener does not express: RotateY around Translate
-        bad = S.RotateY.new(S.Translate.new(sphere, S.vec3(1, 0, 0)), 10.0)
+        # the one nesting the flattener does not express: a ConstantMedium inside another hitable
+        fog = S.ConstantMedium.new(sphere, 0.5, S.Texture.new_constant(S.vec3(1, 1, 1)))
         with pytest.raises(RtError) as e:
-            sc.flatten(S.HitableList.new([bad]))
+            sc.flatten(S.HitableList.new([S.RotateY.new(fog, 10.0)]))
         assert e.value.code == _lib.RT_ERR_UNSUPPORTED
-        assert b"nesting" in _lib.lib().rt_last_error()
+        assert b"ConstantMedium" in _lib.lib().rt_last_error()
+        with pytest.raises(RtError):
+            sc.flatten(S.HitableList.new([S.Translate.new(S.HitableList.new([]), S.vec3(1, 0, 0))]))
+
+
+def test_flatten_writes_any_nesting_as_objects_in_objects(orc):
+    """RotateY(Translate(x)) is a rotate-only object around a sub-tree of one leaf (an infinite box: the source makes no box
+    test between the two) that holds the translate-only object around x; a HitableList of wrapped things is a sub-tree with
+    one leaf per item.  The f64 and fp32 oracles walk the result to the same primitives."""
+    rng = np.random.RandomState(2)
+    with Scene(3) as sc:
+        m = S.Lambertian.new_from_color(S.vec3(0.5, 0.5, 0.5))
+        a = S.RotateY.new(S.Translate.new(S.Cuboid.new(S.vec3(0, 0, 0), S.vec3(1, 2, 3), m), S.vec3(4.0, 0.0, 0.0)), 30.0)
+        b = S.Translate.new(S.HitableList.new([S.RotateY.new(S.Sphere.new(S.vec3(2, 0, 0), 1.0, m), 45.0), S.Sphere.new(S.vec3(0, 3, 0), 1.0, m)]),
+                            S.vec3(-5.0, 0.0, 0.0))
+        flat = sc.flatten(S.HitableList.new([a, b]))
+        obs = [flat.objects[i] for i in range(flat.n_objects)]
+        assert [o.kind for o in obs].count(_lib.RT_OBJ_BVH) == 2
+        outer_a = [o for o in obs if o.kind == _lib.RT_OBJ_BVH and o.xform == _lib.RT_XFORM_ROTATE_Y][0]
+        root = flat.nodes[outer_a.first]
+        assert np.isinf(root.bmin[0]) and np.isinf(root.bmax[2]) and root.left < 0 and root.right == 0
+        inner = flat.objects[~root.left]
+        assert inner.kind == _lib.RT_OBJ_LIST and inner.xform == _lib.RT_XFORM_TRANSLATE and inner.count == 6
+        outer_b = [o for o in obs if o.kind == _lib.RT_OBJ_BVH and o.xform == _lib.RT_XFORM_TRANSLATE][0]
+        node = flat.nodes[outer_b.first]
+        assert node.left >= 0 and node.right >= 0  # two items: an interior node over two leaves
+        o = rng.uniform(-12, 12, size=(4000, 3))
+        d = rng.uniform(-6, 6, size=(4000, 3)) - o
+        p32, t32 = orc.trace_closest(flat, o.astype(np.float32), d.astype(np.float32), mode=orc.ORC_F32_FUSED)
+        p64, t64 = orc.trace_closest(flat, o.astype(np.float32).astype(np.float64), d.astype(np.float32).astype(np.float64), mode=orc.ORC_F64)
+        assert (p32 >= 0).mean() > 0.05 and (p32 == p64).mean() > 0.999
+        hit = (p32 >= 0) & (p32 == p64)
+        assert np.allclose(t32[hit], t64[hit], rtol=1e-4)
+        assert set(np.unique(p32)) >= set(range(8))  # the cuboid's six rects and both spheres are hit
 
 
 def test_perlin_tables_follow_the_degenerate_shuffle():
