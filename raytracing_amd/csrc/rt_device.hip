@@ -46,6 +46,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/rt_abi.h"
@@ -3331,6 +3332,7 @@ struct rt_ctx {
   hipEvent_t ev_launch;      // recorded after the last enqueued render: a launch on another stream waits for it,
   hipStream_t last_stream;   // because all launches of a context share its work counter and slabs
   bool launched;
+  bool verbose;              // RT_VERBOSE was set when the context was made: rt_upload_scene reports what it built and how long each part took
   int opt[RT_OPT_COUNT];     // context options (rt_set_option), indexed by RT_OPT_*; defaults from the environment, read once in rt_create
   double upload_ms[2];       // wall time of the last rt_upload_scene: host build, device copies
 };
@@ -3818,28 +3820,38 @@ struct TreeBuilder {
     collect(n.left, out, media);
     collect(n.right, out, media);
   }
-  int make_leaf(int ref) {
-    const rt_node& n = s->nodes[ref];
+  // A leaf as the builder moves it about: its box beside its reference node, so that the passes over a range of
+  // leaves read memory in order instead of following indices into the scene's node array.
+  struct LeafRec {
+    float bmin[3], bmax[3];
+    int ref;
+  };
+  void make_leaf(const LeafRec& q, size_t at) {
     BuildNode b;
-    for (int c = 0; c < 3; ++c) { b.bmin[c] = n.bmin[c]; b.bmax[c] = n.bmax[c]; }
-    b.top = (*y_top)[(size_t)ref];
+    for (int c = 0; c < 3; ++c) { b.bmin[c] = q.bmin[c]; b.bmax[c] = q.bmax[c]; }
+    b.top = (*y_top)[(size_t)q.ref];
     b.left = b.right = -1;
-    b.ref_node = ref;
-    nodes.push_back(b);
-    return (int)nodes.size() - 1;
+    b.ref_node = q.ref;
+    nodes[at] = b;
   }
   static double half_area(const float* lo, const float* hi) {
     const double dx = (double)hi[0] - lo[0], dy = (double)hi[1] - lo[1], dz = (double)hi[2] - lo[2];
     return dx * dy + dy * dz + dz * dx;
   }
-  // builds the subtree over leaves[begin, end) (reference node indices; reordered in place); returns its node
-  int build(std::vector<int>& leaves, int begin, int end, int depth = 0) {
-    if (end - begin == 1) return make_leaf(leaves[(size_t)begin]);
+  // Builds the subtree over leaves[begin, end) (reordered in place) into nodes[base, base + 2 (end - begin) - 1): the
+  // left subtree's nodes, the right subtree's, then the root, which is what it returns.  A subtree's slots are known
+  // before it is built, so the two halves of a large range are built by two threads.
+  int build(LeafRec* leaves, int begin, int end, size_t base, int depth = 0) {
+    const size_t root_at = base + 2 * (size_t)(end - begin) - 2;
+    if (end - begin == 1) {
+      make_leaf(leaves[begin], root_at);
+      return (int)root_at;
+    }
     const int kBins = 16;
     const bool halve = halve_only || depth > 40;  // (a heuristic split can peel off one leaf at a time: bounded here)
     float cmin[3] = {INFINITY, INFINITY, INFINITY}, cmax[3] = {-INFINITY, -INFINITY, -INFINITY};
     for (int i = begin; i < end; ++i) {
-      const rt_node& n = s->nodes[leaves[(size_t)i]];
+      const LeafRec& n = leaves[i];
       for (int c = 0; c < 3; ++c) {
         const float ctr = 0.5f * n.bmin[c] + 0.5f * n.bmax[c];
         if (ctr < cmin[c]) cmin[c] = ctr;
@@ -3848,67 +3860,83 @@ struct TreeBuilder {
     }
     int best_axis = -1, best_split = 0;
     double best_cost = INFINITY;
-    for (int axis = 0; axis < 3 && !halve; ++axis) {
-      const float extent = cmax[axis] - cmin[axis];
-      if (!(extent > 0.0f) || !std::isfinite(extent)) continue;
-      float blo[kBins][3], bhi[kBins][3];
-      int cnt[kBins];
-      for (int k = 0; k < kBins; ++k) {
-        cnt[k] = 0;
-        for (int c = 0; c < 3; ++c) { blo[k][c] = INFINITY; bhi[k][c] = -INFINITY; }
-      }
-      const float scale = (float)kBins / extent;
-      for (int i = begin; i < end; ++i) {
-        const rt_node& n = s->nodes[leaves[(size_t)i]];
-        int k = (int)((0.5f * n.bmin[axis] + 0.5f * n.bmax[axis] - cmin[axis]) * scale);
-        k = k < 0 ? 0 : (k >= kBins ? kBins - 1 : k);
-        ++cnt[k];
-        for (int c = 0; c < 3; ++c) {
-          if (n.bmin[c] < blo[k][c]) blo[k][c] = n.bmin[c];
-          if (n.bmax[c] > bhi[k][c]) bhi[k][c] = n.bmax[c];
+    if (!halve) {
+      // one pass over the leaves fills the bins of all three axes
+      float blo[3][kBins][3], bhi[3][kBins][3];
+      int cnt[3][kBins];
+      float scale[3];
+      bool usable[3];
+      for (int axis = 0; axis < 3; ++axis) {
+        const float extent = cmax[axis] - cmin[axis];
+        usable[axis] = extent > 0.0f && std::isfinite(extent);
+        scale[axis] = usable[axis] ? (float)kBins / extent : 0.0f;
+        for (int k = 0; k < kBins; ++k) {
+          cnt[axis][k] = 0;
+          for (int c = 0; c < 3; ++c) { blo[axis][k][c] = INFINITY; bhi[axis][k][c] = -INFINITY; }
         }
       }
-      // sweep from the right, then from the left
-      double right_area[kBins];
-      int right_cnt[kBins];
-      float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
-      int c_acc = 0;
-      for (int k = kBins - 1; k > 0; --k) {
-        c_acc += cnt[k];
-        for (int c = 0; c < 3; ++c) { if (blo[k][c] < lo[c]) lo[c] = blo[k][c]; if (bhi[k][c] > hi[c]) hi[c] = bhi[k][c]; }
-        right_cnt[k] = c_acc;
-        right_area[k] = c_acc ? half_area(lo, hi) : 0.0;
+      for (int i = begin; i < end; ++i) {
+        const LeafRec& n = leaves[i];
+        for (int axis = 0; axis < 3; ++axis) {
+          if (!usable[axis]) continue;
+          int k = (int)((0.5f * n.bmin[axis] + 0.5f * n.bmax[axis] - cmin[axis]) * scale[axis]);
+          k = k < 0 ? 0 : (k >= kBins ? kBins - 1 : k);
+          ++cnt[axis][k];
+          for (int c = 0; c < 3; ++c) {
+            if (n.bmin[c] < blo[axis][k][c]) blo[axis][k][c] = n.bmin[c];
+            if (n.bmax[c] > bhi[axis][k][c]) bhi[axis][k][c] = n.bmax[c];
+          }
+        }
       }
-      for (int c = 0; c < 3; ++c) { lo[c] = INFINITY; hi[c] = -INFINITY; }
-      c_acc = 0;
-      for (int k = 0; k < kBins - 1; ++k) {
-        c_acc += cnt[k];
-        for (int c = 0; c < 3; ++c) { if (blo[k][c] < lo[c]) lo[c] = blo[k][c]; if (bhi[k][c] > hi[c]) hi[c] = bhi[k][c]; }
-        if (c_acc == 0 || right_cnt[k + 1] == 0) continue;
-        double cost = half_area(lo, hi) * c_acc + right_area[k + 1] * right_cnt[k + 1];
-        if (!(cost == cost)) cost = INFINITY;  // a box with an infinite side
-        if (cost < best_cost) { best_cost = cost; best_axis = axis; best_split = k + 1; }
+      for (int axis = 0; axis < 3; ++axis) {
+        if (!usable[axis]) continue;
+        // sweep from the right, then from the left
+        double right_area[kBins];
+        int right_cnt[kBins];
+        float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        int c_acc = 0;
+        for (int k = kBins - 1; k > 0; --k) {
+          c_acc += cnt[axis][k];
+          for (int c = 0; c < 3; ++c) { if (blo[axis][k][c] < lo[c]) lo[c] = blo[axis][k][c]; if (bhi[axis][k][c] > hi[c]) hi[c] = bhi[axis][k][c]; }
+          right_cnt[k] = c_acc;
+          right_area[k] = c_acc ? half_area(lo, hi) : 0.0;
+        }
+        for (int c = 0; c < 3; ++c) { lo[c] = INFINITY; hi[c] = -INFINITY; }
+        c_acc = 0;
+        for (int k = 0; k < kBins - 1; ++k) {
+          c_acc += cnt[axis][k];
+          for (int c = 0; c < 3; ++c) { if (blo[axis][k][c] < lo[c]) lo[c] = blo[axis][k][c]; if (bhi[axis][k][c] > hi[c]) hi[c] = bhi[axis][k][c]; }
+          if (c_acc == 0 || right_cnt[k + 1] == 0) continue;
+          double cost = half_area(lo, hi) * c_acc + right_area[k + 1] * right_cnt[k + 1];
+          if (!(cost == cost)) cost = INFINITY;  // a box with an infinite side
+          if (cost < best_cost) { best_cost = cost; best_axis = axis; best_split = k + 1; }
+        }
       }
     }
     int mid = begin + (end - begin) / 2;
     if (best_axis >= 0) {
       const float scale = (float)kBins / (cmax[best_axis] - cmin[best_axis]);
-      const float base = cmin[best_axis];
+      const float base_c = cmin[best_axis];
       const int axis = best_axis, split = best_split;
-      auto bin_of = [&](int ref) {
-        const rt_node& n = s->nodes[ref];
-        int k = (int)((0.5f * n.bmin[axis] + 0.5f * n.bmax[axis] - base) * scale);
+      auto bin_of = [&](const LeafRec& n) {
+        int k = (int)((0.5f * n.bmin[axis] + 0.5f * n.bmax[axis] - base_c) * scale);
         return k < 0 ? 0 : (k >= kBins ? kBins - 1 : k);
       };
-      int* first = leaves.data() + begin;
-      int* last = leaves.data() + end;
-      int* m = std::stable_partition(first, last, [&](int ref) { return bin_of(ref) < split; });
-      mid = (int)(m - leaves.data());
+      LeafRec* m = std::stable_partition(leaves + begin, leaves + end, [&](const LeafRec& n) { return bin_of(n) < split; });
+      mid = (int)(m - leaves);
       if (mid == begin || mid == end) mid = begin + (end - begin) / 2;
     }
     // (all centres in one point, or nothing to gain: halve the range as it stands)
-    const int l = build(leaves, begin, mid, depth + 1);
-    const int r = build(leaves, mid, end, depth + 1);
+    int l = 0, r = 0;
+    const size_t right_base = base + 2 * (size_t)(mid - begin) - 1;
+    if (end - begin >= 32768 && depth < 6) {
+      std::thread left_half([&]() { l = build(leaves, begin, mid, base, depth + 1); });
+      r = build(leaves, mid, end, right_base, depth + 1);
+      left_half.join();
+    } else {
+      l = build(leaves, begin, mid, base, depth + 1);
+      r = build(leaves, mid, end, right_base, depth + 1);
+    }
     BuildNode b;
     for (int c = 0; c < 3; ++c) {
       b.bmin[c] = nodes[(size_t)l].bmin[c] < nodes[(size_t)r].bmin[c] ? nodes[(size_t)l].bmin[c] : nodes[(size_t)r].bmin[c];
@@ -3918,15 +3946,23 @@ struct TreeBuilder {
     b.left = l;
     b.right = r;
     b.ref_node = -1;
-    nodes.push_back(b);
-    return (int)nodes.size() - 1;
+    nodes[root_at] = b;
+    return (int)root_at;
   }
   // the device's tree over the reference leaves under reference node idx
   int build_under(int idx) {
     std::vector<int> leaves;
     collect(idx, &leaves);
     if (leaves.empty()) collect(idx, &leaves, true);  // (a world of media only: the tree keeps them so that it has a leaf)
-    return build(leaves, 0, (int)leaves.size());
+    std::vector<LeafRec> recs(leaves.size());
+    for (size_t i = 0; i < leaves.size(); ++i) {
+      const rt_node& n = s->nodes[leaves[i]];
+      for (int c = 0; c < 3; ++c) { recs[i].bmin[c] = n.bmin[c]; recs[i].bmax[c] = n.bmax[c]; }
+      recs[i].ref = leaves[i];
+    }
+    const size_t base = nodes.size();
+    nodes.resize(base + 2 * recs.size() - 1);
+    return build(recs.data(), 0, (int)recs.size(), base);
   }
 };
 
@@ -4323,6 +4359,7 @@ int rt_create(int device_id, rt_ctx** out) {
     const char* e = kOptSpec[k].env ? getenv(kOptSpec[k].env) : nullptr;
     if (e && *e) ctx->opt[k] = clamp_opt(k, k == RT_OPT_FIXED_ORDER ? 1 : atoi(e));
   }
+  ctx->verbose = getenv("RT_VERBOSE") != nullptr;
   hipDeviceProp_t prop;
   e = hipGetDeviceProperties(&prop, device_id);
   ctx->n_cus = e == hipSuccess ? prop.multiProcessorCount : 0;
@@ -4408,15 +4445,26 @@ int rt_upload_scene_timed(rt_ctx* ctx, const rt_scene* s, double* upload_ms) {
   FW.nested = false;
   rc = FW.walk_tree(0, -1, 0);
   if (rc < 0) return rc;
+  const bool verbose = ctx->verbose;
+  auto t_mark = std::chrono::steady_clock::now();
+  auto lap = [&](const char* what) {
+    if (!verbose) return;
+    const auto now = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "rt_upload_scene: %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(now - t_mark).count());
+    t_mark = now;
+  };
+  lap("checks, frames");
   B.y_top.assign((size_t)s->n_nodes, 0.0f);
   (void)compute_y_top(s, 0, 0, &B.y_top);
-  rc = build_scan(&B, 0, false, false, true, -1);
-  if (rc != RT_OK) return rc;
-  // More than a treelet's worth of leaves: per-lane stack traversal over the
-  // breadth-first nodes; the scan array then keeps only the ConstantMedium nodes.
+  lap("y_top");
+  // More than a treelet's worth of leaves (or a sub-tree anywhere: the scan array would hold an interior node):
+  // per-lane stack traversal over the device's own four-wide tree; the scan array then keeps only the ConstantMedium
+  // nodes, and is only built in full (below) for the scenes that stay on it.
+  bool any_sub_tree = false;
+  for (int i = 0; i < s->n_objects; ++i) any_sub_tree |= s->objects[i].kind == RT_OBJ_BVH;
   const int depth = tree_depth(s, 0);
-  const bool nested = FW.nested || B.incomplete;
-  const bool want_stack = (B.any_interior || nested) && depth <= STACK_DEPTH - 2;
+  const bool nested = FW.nested;
+  const bool want_stack = (B.leaves[0] > kTreeletLeaves || any_sub_tree || nested) && depth <= STACK_DEPTH - 2;
   // the four-wide entries of the interior nodes, and the six-rect records of the list leaves
   TreeBuilder TB;
   TB.s = s;
@@ -4453,7 +4501,9 @@ int rt_upload_scene_timed(rt_ctx* ctx, const rt_scene* s, double* upload_ms) {
     W.box6_index = &box6_index;
     // the world's tree, and the tree of every medium that is bounded by one (walked on its own, after the world's)
     auto build_all = [&]() {
-      root_ref = W.ref_of(TB.build_under(0), &stack_need);
+      const int world_root = TB.build_under(0);
+      lap("SAH tree");
+      root_ref = W.ref_of(world_root, &stack_need);
       for (int i = 0; i < s->n_objects; ++i) {
         if (s->objects[i].kind != RT_OBJ_MEDIUM_BVH) continue;
         int sub = 0;
@@ -4461,6 +4511,7 @@ int rt_upload_scene_timed(rt_ctx* ctx, const rt_scene* s, double* upload_ms) {
         if (sub > stack_need) stack_need = sub;
       }
     };
+    lap("six-rect records");
     build_all();
     if (stack_need + 2 > RT_STACK_MAX) {
       // the heuristic's tree is too deep for a lane's stack: the balanced one over the same leaves
@@ -4470,12 +4521,30 @@ int rt_upload_scene_timed(rt_ctx* ctx, const rt_scene* s, double* upload_ms) {
       build_all();
     }
     if (W.out.size() > (size_t)BN_INDEX_MASK) return rt::set_error(RT_ERR_UNSUPPORTED, "too many nodes");
+    lap("four-wide nodes");
   }
   // a tree whose walk could need more stack than a lane has (LDS part + private part) takes the scan
   const bool stack_mode = want_stack && stack_need + 2 <= RT_STACK_MAX;
   if (nested && !stack_mode)
     return rt::set_error(RT_ERR_UNSUPPORTED, "objects inside objects (or a medium bounded by a sub-tree) need the per-lane stack traversal, and this scene's "
                                              "trees are deeper than its stack of 64 entries allows");
+  if (stack_mode) {
+    // of the scan array only the media's nodes are needed: the world tree's ConstantMedium leaves, in depth-first order
+    std::vector<int> world_leaves;
+    TB.collect(0, &world_leaves, true);
+    for (size_t i = 0; i < world_leaves.size(); ++i) {
+      const rt_node& n = s->nodes[world_leaves[i]];
+      if (n.right == 0 && s->objects[~n.left].kind >= RT_OBJ_MEDIUM) {
+        rc = build_scan(&B, world_leaves[i], false, true, false, -1);
+        if (rc != RT_OK) return rc;
+      }
+    }
+    lap("media nodes");
+  } else {
+    rc = build_scan(&B, 0, false, false, true, -1);
+    if (rc != RT_OK) return rc;
+    lap("scan array");
+  }
   std::vector<BNode> bnodes;
   std::vector<int> prim_rank((size_t)s->n_prims, 0);
   std::vector<ScanNode> media_scan;
@@ -4494,6 +4563,7 @@ int rt_upload_scene_timed(rt_ctx* ctx, const rt_scene* s, double* upload_ms) {
       }
       i += (B.out[i].kind == K_OBJ_BVH) ? 1 : (size_t)slots;
     }
+    lap("node copies, ranks");
   }
   const std::vector<ScanNode>& scan = stack_mode ? media_scan : B.out;
   const auto t_built = std::chrono::steady_clock::now();
@@ -4615,7 +4685,8 @@ int rt_upload_scene_timed(rt_ctx* ctx, const rt_scene* s, double* upload_ms) {
   d.stack_mode = stack_mode ? 1 : 0;
   d.stack_depth = stack_mode ? stack_need + 2 : 0;  // what the deepest walk can have in use, and a margin
   d.stack_lds = d.stack_depth;  // (the trace kernel's; the render kernel's LDS part is set per launch)
-  if (getenv("RT_VERBOSE"))
+  lap("records, copies to the device");
+  if (verbose)
     std::fprintf(stderr, "rt_upload_scene: %d nodes, %d primitives, reference tree depth %d; traversal %s; four-wide entries %zu, stack entries per lane %d (%s tree)\n",
                  s->n_nodes, s->n_prims, depth, stack_mode ? "stack" : (d.flat ? "flat" : "scan"), W.out.size(), d.stack_depth,
                  TB.halve_only ? "balanced" : "surface-area");
