@@ -1246,13 +1246,16 @@ struct Surface {
 // (hitable.rs:442).  `q` is the hit primitive's DevPrim.
 // A primitive inside more than one object (DP_CHAINED; `prim` is its index) goes through its objects one by one,
 // outermost first on the way in and innermost first on the way back, as the nested hit() calls of the source do.
+// CHAINS: the code for such primitives is only compiled into the builds that scenes with them are given (the render
+// kernels' most general build, and the trace kernel), so that the other builds keep their registers.
+template <bool CHAINS>
 __device__ __forceinline__ Surface finalize_hit(const DevScene& S, const DevPrim& q, int prim, const RayF& w, float t, bool has_spheres) {
   Surface s;
   const int xform = (q.flags >> DP_XFORM_SHIFT) & 3;
   RayF r = to_object_frame<false>(w, xform, q.sin_t, q.cos_t, q.off[0], q.off[1], q.off[2]);
-  const bool chained = S.has_chains != 0 && (q.flags & DP_CHAINED) != 0;
+  const bool chained = CHAINS && S.has_chains != 0 && (q.flags & DP_CHAINED) != 0;
   int ch_first = 0, ch_len = 0;
-  if (S.has_chains != 0 && __ballot(chained) != 0ull) {  // (wave-uniform: scenes without such nestings never come here)
+  if (CHAINS && S.has_chains != 0 && __ballot(chained) != 0ull) {  // (wave-uniform: scenes without such nestings never come here)
     if (chained) {
       const int ob = S.prim_obj[prim];
       ch_first = S.obj_chain[2 * ob];
@@ -1288,7 +1291,7 @@ __device__ __forceinline__ Surface finalize_hit(const DevScene& S, const DevPrim
   nrm.x = ro ? fmaf(q.cos_t, nl.x, q.sin_t * nl.z) : nl.x;
   nrm.z = ro ? fmaf(-q.sin_t, nl.x, q.cos_t * nl.z) : nl.z;
   p = sel3(tr, f3(p.x + q.off[0], p.y + q.off[1], p.z + q.off[2]), p);
-  if (S.has_chains != 0 && __ballot(chained) != 0ull) {
+  if (CHAINS && S.has_chains != 0 && __ballot(chained) != 0ull) {
     if (chained) {
       for (int i = ch_len - 1; i >= 0; --i) {
         const rt_object o = S.objects[S.chain_objs[ch_first + i]];
@@ -1334,7 +1337,7 @@ __global__ void __launch_bounds__(256) trace_kernel(DevScene S, const float* __r
         Surface s;
         s.p = f3(0, 0, 0);
         s.normal = f3(0, 0, 0);
-        if (h.prim >= 0) s = finalize_hit(S, S.dprims[h.prim], h.prim, w, h.t, S.has_spheres != 0);
+        if (h.prim >= 0) s = finalize_hit<true>(S, S.dprims[h.prim], h.prim, w, h.t, S.has_spheres != 0);
         if (normal) { normal[3 * idx] = s.normal.x; normal[3 * idx + 1] = s.normal.y; normal[3 * idx + 2] = s.normal.z; }
         if (p_out) { p_out[3 * idx] = s.p.x; p_out[3 * idx + 1] = s.p.y; p_out[3 * idx + 2] = s.p.z; }
       }
@@ -1782,7 +1785,7 @@ __device__ __forceinline__ Shaded shade_vertex(const DevScene& S, const float4* 
     __builtin_memcpy((char*)&q + 32, &q2, 16);
     __builtin_memcpy((char*)&q + 48, &q3, 16);
   }
-  const Surface sf = finalize_hit(S, q, hit ? h.prim : 0, ray, h.t, S.has_spheres != 0);
+  const Surface sf = finalize_hit<GENERAL == 3>(S, q, hit ? h.prim : 0, ray, h.t, S.has_spheres != 0);
   const int mat_type = (q.flags >> DP_MAT_SHIFT) & 7;
   F3 color = f3(q.color[0], q.color[1], q.color[2]);
   if (STATS) cnt.hits += hit;
@@ -2438,7 +2441,7 @@ __global__ void __launch_bounds__(64, GENERAL < 2 ? RT_STACK_WAVES : 5) render_s
         const PathRng rng = {pixel_id, sample, (unsigned)depth, key0, key1};
         scan_range<STATS, true, true, 0>(S, 0, S.n_scan, act, RT_WORLD_RAY(), a_t_min, INFINITY, rng, T.best, cnt);
       }
-      if (GENERAL != 0 && S.n_media_bvh > 0) {
+      if (GENERAL == 3 && S.n_media_bvh > 0) {
         const PathRng rng = {pixel_id, sample, (unsigned)depth, key0, key1};
         media_bvh_pass<STATS>(S, stk, act, RT_WORLD_RAY(), a_t_min, INFINITY, rng, T.best, cnt);
       }
@@ -4706,8 +4709,9 @@ int rt_upload_scene_timed(rt_ctx* ctx, const rt_scene* s, double* upload_ms) {
   if ((rc = upload(&ctx->d_lights, s->lights, (size_t)s->n_lights)) != RT_OK) return rc;
   d.lights = (const rt_light*)ctx->d_lights;
   d.light_general = (s->n_lights > 1 || (s->n_lights == 1 && s->lights[0].type != RT_LIGHT_XZ_RECT)) ? 1 : 0;
-  // (the general light code is compiled into build 3 only, so that the other builds keep their registers)
-  ctx->general = d.light_general ? 3 : textured ? 2 : ((!B.media.empty() || (mat_mask & ~((1 << RT_MAT_LAMBERTIAN) | (1 << RT_MAT_DIFFUSE_LIGHT))) != 0) ? 1 : 0);
+  // (the general light code is compiled into build 3 only, so that the other builds keep their registers; so is the code
+  // for primitives inside more than one object and for media bounded by a sub-tree)
+  ctx->general = (d.light_general || has_chains || d.n_media_bvh > 0) ? 3 : textured ? 2 : ((!B.media.empty() || (mat_mask & ~((1 << RT_MAT_LAMBERTIAN) | (1 << RT_MAT_DIFFUSE_LIGHT))) != 0) ? 1 : 0);
   ctx->has_scene = true;
   const auto t_end = std::chrono::steady_clock::now();
   ctx->upload_ms[0] = std::chrono::duration<double, std::milli>(t_built - t_begin).count();
