@@ -357,7 +357,13 @@ int rt_render(rt_ctx* ctx, const rt_camera* cam, const rt_render_params* params,
  * Scenes of at most 16 leaves and scenes on the skip-link scan give the same bits
  * on every run.  Scenes on the per-lane stack traversal (larger trees) have no
  * partial images: their work items add tile sums into the zeroed output with
- * hardware float adds, so the last bits of a sum can differ from run to run. */
+ * hardware float adds, so the last bits of a sum can differ from run to run
+ * (RT_OPT_FIXED_ORDER gives fixed bits).  Those adds are only dependable on ordinary
+ * device allocations, so the call asks the runtime what kind of memory each output
+ * buffer is: anything but plain hipMalloc memory (host-mapped, managed, unknown to
+ * the runtime) is written the RT_OPT_FIXED_ORDER way, with plain stores.  Device
+ * memory allocated fine-grained (hipExtMallocWithFlags) reports as plain device
+ * memory: set RT_OPT_FIXED_ORDER for such buffers. */
 int rt_render_device(rt_ctx* ctx, const rt_camera* cam, const rt_render_params* params,
                      float* d_sum_rgb, float* d_sumsq_rgb_or_null, void* hip_stream);
 

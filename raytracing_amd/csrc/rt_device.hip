@@ -670,13 +670,80 @@ __device__ __forceinline__ int wave_min_i32(int v) {
   return v;
 }
 
-// The deferred scan of a flat array that leaves media out (the Cornell box; rt_trace_closest): every slot it tests is a
-// single rect, a single sphere, a list or a list under Translate/RotateY, so the loop needs none of scan_range's bookkeeping for skipping lanes,
-// sub-trees and media.  Scalar instructions take the same issue slots as vector ones (tools/probe_valu.sh), and
-// the general loop spends about 25 of them per leaf on its dispatch.  Same tests in the same order as scan_range.
+// ConstantMedium::hit, hitable.rs:560-598 (commented out in the reference), for the K_MEDIUM node `n` at scan[i] and the
+// lanes in `on` (some lane is): the two boundary searches, then the draw.  A hit replaces `best` unless best is nearer.
 template <bool STATS>
+__device__ __forceinline__ void medium_node(const DevScene& S, int i, const ScanNode& n, bool on, const RayF& r, float t_min, float t_max,
+                                            const PathRng& rng, Hit& best, Counters& cnt) {
+  const RayF q = to_object_frame<true, true>(r, n.b >> 24, n.f[0], n.f[1], n.f[2], n.f[3], n.f[4]);
+  const bool box6 = (n.b & LIST_IS_BOX6) != 0;
+  const ScanNode ext = load_node(S.scan, n.skip - 1);  // density, ordinal, DevPrim index
+  Hit b1, b2;
+  b1.t = 3.402823466e+38f; b1.prim = -1;
+  b2.t = 3.402823466e+38f; b2.prim = -1;
+  const int n_boundary = n.b & 0x7fffff;
+  const rt_prim bq = load_prim_uniform(S.prims, n.a);
+  if (!box6 && n_boundary == 1 && (bq.type & RT_PRIM_TYPE_MASK) == RT_PRIM_SPHERE) {
+    // A sphere as the boundary: the two searches below are the two roots of one quadratic, so it is solved once.
+    // Each search takes the nearer root inside its interval, else the farther one, exactly as Sphere::hit does.
+    float h, t_near, t_far;
+    sphere_roots(bq.f, q, h, t_near, t_far);
+    if (STATS) cnt.sphere_tests += on ? 2u : 0u;
+    const float big = 3.402823466e+38f;
+    const bool n1 = (t_near < big) & (t_near > -big), f1 = (t_far < big) & (t_far > -big);
+    const bool v1 = on & (h > 0.0f) & (n1 | f1);
+    b1.t = v1 ? (n1 ? t_near : t_far) : b1.t;
+    b1.prim = v1 ? n.a : -1;
+    float t_next = b1.t + 0.0001f;
+    {
+      const int bits = __float_as_int(b1.t);
+      const float up = __int_as_float(bits >= 0 ? bits + 1 : (bits == (int)0x80000000 ? 1 : bits - 1));
+      t_next = t_next > b1.t ? t_next : up;
+    }
+    const bool n2 = (t_near < big) & (t_near > t_next), f2 = (t_far < big) & (t_far > t_next);
+    const bool v2 = on & (h > 0.0f) & (n2 | f2);
+    b2.t = v2 ? (n2 ? t_near : t_far) : b2.t;
+    b2.prim = v2 ? n.a : -1;
+  } else if (box6) {
+    box6_two_searches<STATS>(S.scan, i, n.a, on, q, b1, b2, cnt);
+  } else {
+    list_test<STATS>(S.prims, n.a, n_boundary, on, q, -3.402823466e+38f, 3.402823466e+38f, b1, cnt);
+    // hitable.rs:566 searches on from rec1.t + 0.0001.  Not in the reference, which works in f64: beyond t = 2048 that
+    // sum is rec1.t itself in fp32 and a rect (whose test accepts t == t_min) would be found again, so the search
+    // starts at the next float above rec1.t at least.
+    float t_next = b1.t + 0.0001f;
+    {
+      const int bits = __float_as_int(b1.t);
+      const float up = __int_as_float(bits >= 0 ? bits + 1 : (bits == (int)0x80000000 ? 1 : bits - 1));
+      t_next = t_next > b1.t ? t_next : up;
+    }
+    list_test<STATS>(S.prims, n.a, n_boundary, on, q, t_next, 3.402823466e+38f, b2, cnt);
+  }
+  float t1 = b1.t, t2 = b2.t;
+  t1 = t1 < t_min ? t_min : t1;
+  t2 = t2 > t_max ? t_max : t2;
+  bool ok = on & (b1.prim >= 0) & (b2.prim >= 0) & !(t1 >= t2);
+  if (STATS) cnt.instance_ops += on;
+  if (__ballot(ok) != 0ull) {  // the draw is only made where some ray crosses the medium
+    t1 = t1 < 0.0f ? 0.0f : t1;
+    const float dlen = sqrtf(dot3(r.d, r.d));
+    const float inside = (t2 - t1) * dlen;
+    const U4 mw = philox4x32_10(rng.pixel, rng.sample, rng.depth, 4096u + (unsigned)ext.a, rng.key0, rng.key1);
+    const float hit_distance = -(1.0f / ext.f[0]) * __logf(u01(mw.x));
+    const float t = t1 + hit_distance / dlen;
+    ok &= (hit_distance < inside) & !(best.t < t);
+    best.t = ok ? t : best.t;
+    best.prim = ok ? ext.b : best.prim;
+  }
+}
+
+// The deferred scan of a flat array (the Cornell box, with MEDIA also its variants with smoke; rt_trace_closest): every slot
+// it tests is a single rect, a single sphere, a list, a list under Translate/RotateY or a ConstantMedium, so the loop needs
+// none of scan_range's bookkeeping for skipping lanes and sub-trees.  Scalar instructions take the same issue slots as vector ones (tools/probe_valu.sh), and
+// the general loop spends about 25 of them per leaf on its dispatch.  Same tests in the same order as scan_range.
+template <bool STATS, bool MEDIA = false>
 __device__ __forceinline__ void scan_flat_lean(const DevScene& S, int end, bool active, const RayF& r, float t_min, float t_max, Hit& best,
-                                               Counters& cnt) {
+                                               Counters& cnt, const PathRng* rng = nullptr) {
   const bool on_t = STATS ? active : true;  // the caller masks the result with `active` (trace_scan's `got`)
   if (end <= 0) return;
   int i = 0;
@@ -702,11 +769,13 @@ __device__ __forceinline__ void scan_flat_lean(const DevScene& S, int end, bool 
     } else if (kind == K_LIST) {
       if (n.b & LIST_IS_BOX6) box6_cand<STATS>(S.scan, i, n.a, on_t, r, t_min, t_max, best.t, cand_t, cand_prim, take, cnt);
       else list_cand<STATS>(S.prims, n.a, n.b & 0x7fffff, on_t, r, t_min, t_max, best.t, cand_t, cand_prim, take, cnt);
-    } else if (kind == K_OBJ_LIST) {  // (what is left is a ConstantMedium in a query that leaves media out: rt_trace_closest)
+    } else if (kind == K_OBJ_LIST) {  // (what is left is a ConstantMedium: skipped in a query that leaves media out, rt_trace_closest)
       const RayF q = to_object_frame<true, true>(r, n.b >> 24, n.f[0], n.f[1], n.f[2], n.f[3], n.f[4]);
       if (STATS) cnt.instance_ops += active;
       if (n.b & LIST_IS_BOX6) box6_cand<STATS>(S.scan, i, n.a, on_t, q, t_min, t_max, best.t, cand_t, cand_prim, take, cnt);
       else list_cand<STATS>(S.prims, n.a, n.b & 0x7fffff, on_t, q, t_min, t_max, best.t, cand_t, cand_prim, take, cnt);
+    } else if (MEDIA && kind == K_MEDIUM) {
+      if (__ballot(active) != 0ull) medium_node<STATS>(S, i, n, active, r, t_min, t_max, *rng, best, cnt);
     }
     best.t = take ? cand_t : best.t;
     best.prim = take ? cand_prim : best.prim;
@@ -796,69 +865,7 @@ __device__ __forceinline__ void scan_range(const DevScene& S, int begin, int end
       }
     }
     else if (MEDIA && kind == K_MEDIUM && LEVEL == 0) {
-      // ConstantMedium::hit, hitable.rs:560-598 (commented out in the reference).
-      if (__ballot(on) != 0ull) {
-        const RayF q = to_object_frame<true, true>(r, n.b >> 24, n.f[0], n.f[1], n.f[2], n.f[3], n.f[4]);
-        const bool box6 = (n.b & LIST_IS_BOX6) != 0;
-        const ScanNode ext = load_node(S.scan, n.skip - 1);  // density, ordinal, DevPrim index
-        Hit b1, b2;
-        b1.t = 3.402823466e+38f; b1.prim = -1;
-        b2.t = 3.402823466e+38f; b2.prim = -1;
-        const int n_boundary = n.b & 0x7fffff;
-        const rt_prim bq = load_prim_uniform(S.prims, n.a);
-        if (!box6 && n_boundary == 1 && (bq.type & RT_PRIM_TYPE_MASK) == RT_PRIM_SPHERE) {
-          // A sphere as the boundary: the two searches below are the two roots of one quadratic, so it is solved once.
-          // Each search takes the nearer root inside its interval, else the farther one, exactly as Sphere::hit does.
-          float h, t_near, t_far;
-          sphere_roots(bq.f, q, h, t_near, t_far);
-          if (STATS) cnt.sphere_tests += on ? 2u : 0u;
-          const float big = 3.402823466e+38f;
-          const bool n1 = (t_near < big) & (t_near > -big), f1 = (t_far < big) & (t_far > -big);
-          const bool v1 = on & (h > 0.0f) & (n1 | f1);
-          b1.t = v1 ? (n1 ? t_near : t_far) : b1.t;
-          b1.prim = v1 ? n.a : -1;
-          float t_next = b1.t + 0.0001f;
-          {
-            const int bits = __float_as_int(b1.t);
-            const float up = __int_as_float(bits >= 0 ? bits + 1 : (bits == (int)0x80000000 ? 1 : bits - 1));
-            t_next = t_next > b1.t ? t_next : up;
-          }
-          const bool n2 = (t_near < big) & (t_near > t_next), f2 = (t_far < big) & (t_far > t_next);
-          const bool v2 = on & (h > 0.0f) & (n2 | f2);
-          b2.t = v2 ? (n2 ? t_near : t_far) : b2.t;
-          b2.prim = v2 ? n.a : -1;
-        } else if (box6) {
-          box6_two_searches<STATS>(S.scan, i, n.a, on, q, b1, b2, cnt);
-        } else {
-          list_test<STATS>(S.prims, n.a, n_boundary, on, q, -3.402823466e+38f, 3.402823466e+38f, b1, cnt);
-          // hitable.rs:566 searches on from rec1.t + 0.0001.  Not in the reference, which works in f64: beyond t = 2048 that
-          // sum is rec1.t itself in fp32 and a rect (whose test accepts t == t_min) would be found again, so the search
-          // starts at the next float above rec1.t at least.
-          float t_next = b1.t + 0.0001f;
-          {
-            const int bits = __float_as_int(b1.t);
-            const float up = __int_as_float(bits >= 0 ? bits + 1 : (bits == (int)0x80000000 ? 1 : bits - 1));
-            t_next = t_next > b1.t ? t_next : up;
-          }
-          list_test<STATS>(S.prims, n.a, n_boundary, on, q, t_next, 3.402823466e+38f, b2, cnt);
-        }
-        float t1 = b1.t, t2 = b2.t;
-        t1 = t1 < t_min ? t_min : t1;
-        t2 = t2 > t_max ? t_max : t2;
-        bool ok = on & (b1.prim >= 0) & (b2.prim >= 0) & !(t1 >= t2);
-        if (STATS) cnt.instance_ops += on;
-        if (__ballot(ok) != 0ull) {  // the draw is only made where some ray crosses the medium
-          t1 = t1 < 0.0f ? 0.0f : t1;
-          const float dlen = sqrtf(dot3(r.d, r.d));
-          const float inside = (t2 - t1) * dlen;
-          const U4 mw = philox4x32_10(rng.pixel, rng.sample, rng.depth, 4096u + (unsigned)ext.a, rng.key0, rng.key1);
-          const float hit_distance = -(1.0f / ext.f[0]) * __logf(u01(mw.x));
-          const float t = t1 + hit_distance / dlen;
-          ok &= (hit_distance < inside) & !(best.t < t);
-          best.t = ok ? t : best.t;
-          best.prim = ok ? ext.b : best.prim;
-        }
-      }
+      if (__ballot(on) != 0ull) medium_node<STATS>(S, i, n, on, r, t_min, t_max, rng, best, cnt);
     }
     best.t = take ? cand_t : best.t;
     best.prim = take ? cand_prim : best.prim;
@@ -1219,8 +1226,7 @@ __device__ __forceinline__ Hit trace_scan(const DevScene& S, unsigned* stk, cons
     // winner among the box-tested candidates, each of which is one of the
     // candidates it beat.  If it fails for any lane, the wave redoes the scan
     // with every box test in place.
-    if (!MEDIA) scan_flat_lean<STATS>(S, S.n_scan, active, w, t_min, t_max, best, cnt);
-    else scan_range<STATS, true, MEDIA, 0, true>(S, 0, S.n_scan, active, w, t_min, t_max, rng, best, cnt);
+    scan_flat_lean<STATS, MEDIA>(S, S.n_scan, active, w, t_min, t_max, best, cnt, &rng);
     const bool got = active & (best.prim >= 0);
     const float4* lb = leaf_box + 2 * (got ? best.prim : 0);
     const float4 b0 = lb[0], b1 = lb[1];
@@ -4094,6 +4100,16 @@ int stage(rt_ctx* ctx, int slot, size_t bytes, void** out) {
   return RT_OK;
 }
 
+// True for memory from hipMalloc on some device; false for host-mapped, managed and unregistered memory.
+static bool plain_device_memory(const void* p) {
+  hipPointerAttribute_t at;
+  if (hipPointerGetAttributes(&at, p) != hipSuccess) {
+    (void)hipGetLastError();  // the failed query must not show up as the launch's error
+    return false;
+  }
+  return at.type == hipMemoryTypeDevice && !at.isManaged;
+}
+
 // no_alloc: the work counter and the slabs are this device's `scratch` array; a launch whose slabs do not fit is refused.
 int launch_render(rt_ctx* ctx, const rt_camera* cam, const rt_render_params* p, float* d_sum, float* d_sumsq, bool stats, hipStream_t stream,
                   bool no_alloc = false) {
@@ -4129,8 +4145,13 @@ int launch_render(rt_ctx* ctx, const rt_camera* cam, const rt_render_params* p, 
   // (The order of those adds depends on scheduling, so a pixel's sum can differ in its last bits from run to run;
   // the flat and scan kernels keep their fixed order.)
   // RT_OPT_FIXED_ORDER gives the partial images back, and one open item per wave: bit-reproducible sums.
-  A.accumulate = (trav == TRAV_STACK && !ctx->opt[RT_OPT_FIXED_ORDER]) ? 1 : 0;
-  A.max_slots = ctx->opt[RT_OPT_FIXED_ORDER] ? 1 : 8;
+  // The hardware float adds are only dependable on ordinary device allocations (hipMalloc): on host-mapped, managed or
+  // unknown memory they can be lost without an error, so an output buffer of any other kind takes the fixed-order path,
+  // which writes it with plain stores.
+  bool fixed_order = ctx->opt[RT_OPT_FIXED_ORDER] != 0;
+  if (trav == TRAV_STACK && !fixed_order && !(plain_device_memory(d_sum) && (!d_sumsq || plain_device_memory(d_sumsq)))) fixed_order = true;
+  A.accumulate = (trav == TRAV_STACK && !fixed_order) ? 1 : 0;
+  A.max_slots = fixed_order ? 1 : 8;
   const long long want_items = 256LL * 24 * ctx->opt[RT_OPT_ITEM_ROUNDS];
   int min_chunk_spp = A.accumulate ? 16 : 32;
   // a small launch of the stack kernel (fewer items than a few per wave slot the chip has) takes smaller items, down to

@@ -81,6 +81,7 @@ class HipMemory(object):
         self.hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
         self.hip.hipMemset.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
         self.live = []
+        self.live_host = []
 
     def alloc(self, nbytes, fill_byte=0xFF):
         p = self.C.c_void_p()
@@ -89,19 +90,33 @@ class HipMemory(object):
         self.live.append(p)
         return p.value
 
+    def alloc_host_mapped(self, nbytes, fill_byte=0xFF):
+        """Pinned host memory the device reaches through the same address (not an
+        ordinary device allocation)."""
+        p = self.C.c_void_p()
+        self.hip.hipHostMalloc.argtypes = [self.C.POINTER(self.C.c_void_p), self.C.c_size_t, self.C.c_uint]
+        assert self.hip.hipHostMalloc(self.C.byref(p), nbytes, 0) == 0
+        self.C.memset(p.value, fill_byte, nbytes)
+        self.live_host.append(p)
+        return p.value
+
     def sync(self):
         assert self.hip.hipDeviceSynchronize() == 0
 
     def to_host(self, ptr, dtype, count):
         out = np.empty(count, dtype=dtype)
         self.sync()
-        assert self.hip.hipMemcpy(out.ctypes.data, ptr, out.nbytes, 2) == 0  # hipMemcpyDeviceToHost
+        assert self.hip.hipMemcpy(out.ctypes.data, ptr, out.nbytes, 4) == 0  # hipMemcpyDefault: device or mapped host memory
         return out
 
     def free_all(self):
         for p in self.live:
             self.hip.hipFree(p)
         self.live = []
+        self.hip.hipHostFree.argtypes = [self.C.c_void_p]
+        for p in self.live_host:
+            self.hip.hipHostFree(p)
+        self.live_host = []
 
 
 @pytest.fixture()

@@ -92,6 +92,30 @@ def test_fixed_order_option_gives_equal_bits(gpu):
     assert np.allclose(free, a, rtol=1e-5, atol=1e-4)
 
 
+def test_output_in_host_mapped_memory_is_written_with_plain_stores(gpu, hipmem):
+    """The stack kernel's float atomics are only dependable on ordinary device
+    allocations.  rt_render_device looks at what kind of memory it is given: a
+    host-mapped output buffer gets the fixed-order path (partial images, plain stores),
+    so its sums equal RT_OPT_FIXED_ORDER's in device memory bit for bit."""
+    cam, flat = _field_150()
+    gpu.upload_scene(flat)
+    p = make_params(160, 96, 128, seed=5)
+    n = 160 * 96 * 3
+    gpu.set_option(RT_OPT_FIXED_ORDER, 1)
+    try:
+        want, want2 = gpu.render(cam, p, want_sumsq=True)
+    finally:
+        gpu.set_option(RT_OPT_FIXED_ORDER, 0)
+    for both_mapped in (True, False):
+        a = hipmem.alloc_host_mapped(n * 4)
+        b = hipmem.alloc_host_mapped(n * 4) if both_mapped else hipmem.alloc(n * 4)
+        gpu.render_device(cam, p, b, a, None)  # the sums in b, the sums of squares in the mapped buffer
+        got = hipmem.to_host(b, np.float32, n).reshape(want.shape)
+        got2 = hipmem.to_host(a, np.float32, n).reshape(want.shape)
+        assert np.array_equal(got, want) and np.array_equal(got2, want2), both_mapped
+    hipmem.free_all()
+
+
 def test_tuning_options_are_clamped_and_cannot_hang_the_kernel(gpu):
     """A threshold of more than 64 lanes in 64 could never be met: the traversal phase
     would never hand the wave back to the shading code.  The options clamp to their

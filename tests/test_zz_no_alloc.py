@@ -80,3 +80,29 @@ def test_noalloc_on_a_tree_scene(gpu, hipmem):
         (ref, _), (got, _) = _both(gpu, hipmem, cam, p)
         assert np.isfinite(ref).all() and ref.sum() > 0
         assert np.allclose(ref, got, rtol=1e-5, atol=1e-4)
+
+
+def test_noalloc_when_the_scratch_cannot_hold_the_stacks(gpu, hipmem):
+    """Partial images (RT_OPT_FIXED_ORDER) of 1024x768 at 128 spp take 56.6 MB of the
+    64 MiB scratch; with one stack entry wanted in LDS the 8192 waves' stack regions
+    would need 4 MiB per further entry, so only two entries fit and the rest of each
+    lane's stack has to stay in LDS: slower, same bits as rt_render_device."""
+    from raytracing_amd import Scene, make_params
+    from raytracing_amd._lib import RT_OPT_FIXED_ORDER, RT_OPT_STACK_LDS_ENTRIES
+    from test_gpu_materials import _sphere_field
+    with Scene(78) as sc:
+        cam, world = _sphere_field(600, 4, glass_and_metal=True)
+        sc.light_xz_rect(-3.0, 3.0, -3.0, 3.0, 6.0)
+        flat = sc.flatten(world)
+    gpu.upload_scene(flat)
+    saved = gpu.get_option(RT_OPT_STACK_LDS_ENTRIES)
+    gpu.set_option(RT_OPT_FIXED_ORDER, 1)
+    gpu.set_option(RT_OPT_STACK_LDS_ENTRIES, 1)
+    try:
+        for p in (make_params(1024, 768, 128, seed=8), make_params(64, 40, 20, seed=9)):
+            (ref, _), (got, _) = _both(gpu, hipmem, cam, p)
+            assert np.isfinite(ref).all() and ref.sum() > 0
+            assert np.array_equal(ref, got)
+    finally:
+        gpu.set_option(RT_OPT_FIXED_ORDER, 0)
+        gpu.set_option(RT_OPT_STACK_LDS_ENTRIES, saved)
