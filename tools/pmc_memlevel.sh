@@ -33,6 +33,6 @@ def show(what, c):
 st = launches("stress", lambda k: 'render_' in k and 'kernel<false' in k)
 if st:
     show("render kernel, 2^20 spheres 3840x2160 @ 64 (the launch with the fewest fabric reads)", min(st, key=lambda kv: kv[1]['TCC_EA0_RDREQ_sum'])[1])
-for (i, name), c in launches("calib", lambda k: 'gather_lines' in k):
+for (i, name), c in launches("calib", lambda k: 'gather_lines' in k or 'chase_lines' in k):
     show("calibration launch %d %s" % (i, name.split('(')[0]), c)
 PY
