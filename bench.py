@@ -171,7 +171,7 @@ def main():
     # HBM bytes per launch of the dominant kernel from a committed PMC profile of this exact workload
     # (rocprofv3 FETCH_SIZE / WRITE_SIZE passes; tools/profile.sh), null for any other workload
     traffic = None
-    traffic_file = os.path.join(ROOT, "profiles", "r2", "traffic.json")
+    traffic_file = os.path.join(ROOT, "profiles", "r3", "traffic.json")
     if (nx, ny, spp, world) == (1024, 1024, 1000, 1) and os.path.exists(traffic_file):
         for name, t in json.load(open(traffic_file)).items():
             if name.startswith("render_kernel"):
@@ -233,7 +233,7 @@ def main():
                           "per-event constant) / kernel time (HIP events on the launch stream)",
             "rays_per_path": executed["rays_per_path"],
             "algorithmic_hbm_bytes_per_launch": nx * ny * 12,
-            "traffic_note": "HBM bytes per launch from the PMC profile of this workload (profiles/r2/traffic.json); the only "
+            "traffic_note": "HBM bytes per launch from the PMC profile of this workload (profiles/r3/traffic.json); the only "
                             "algorithmic HBM stream is the nx*ny*12-byte image",
             "note": "no MFMA and no HBM stream on this path: the scene is 2 KB and lives in SGPRs/LDS; "
                     "the bound is the fp32 vector ALU",

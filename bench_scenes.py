@@ -125,7 +125,7 @@ def measure_config(cfg, device_index=0, reps=3, cpu=True, spheres=1 << 20, seed=
     if cfg["scene"] == "stress":
         # The traversal of this scene is the memory-side configuration: its fabric traffic comes from the committed PMC
         # profile of this exact launch (bytes per launch do not depend on the run), divided by this run's kernel time.
-        tf = os.path.join(ROOT, "profiles", "r2", "stress_traffic.json")
+        tf = os.path.join(ROOT, "profiles", "r3", "stress_traffic.json")
         mem = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "achieved": None, "frac": None, "traffic": None,
                "request_bytes_per_launch": int(32 * st.node_tests + 20 * st.sphere_tests),
                "note": "achieved = fabric read bytes per launch (FETCH_SIZE x 2, PMC profile of the same launch) / kernel time; "
@@ -426,7 +426,7 @@ def main():
     roofline["frac"] = round(roofline["achieved"] / roofline["peak"], 4)
     if args.scene == "stress":
         # request bytes are not traffic (nearly all are served by L1/L2): they are listed, not compared with a peak; the
-        # fabric traffic of this scene comes from the PMC profile (tools/profile_stress.sh, profiles/r2/stress_summary.txt)
+        # fabric traffic of this scene comes from the PMC profile (tools/profile_stress.sh, profiles/r3/stress_summary.txt)
         roofline["request_bytes_per_launch"] = int(32.0 * node_tests + 20.0 * sphere_tests)
     line = {
         "scene": args.scene, "nx": args.nx, "ny": args.ny, "spp": args.spp, "nodes": flat.n_nodes, "prims": flat.n_prims,
