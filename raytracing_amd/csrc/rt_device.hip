@@ -145,6 +145,8 @@ struct DevScene {
   // ConstantMedia whose boundary is a sub-tree (RT_OBJ_MEDIUM_BVH): walked after the tree like the others, by their own code
   const struct MediumBvh* media_bvh;
   int n_media_bvh;
+  const struct ScanNode* media_sph;  // see media_sphere_pass; n_media_sph > 0 only when EVERY medium of the scan array has such a record
+  int n_media_sph;
   const rt_node* ref_nodes;  // the node array as it was passed in (trace64_kernel walks it the reference's way)
   int n_ref_nodes;
   int stack_mode;
@@ -670,8 +672,56 @@ __device__ __forceinline__ int wave_min_i32(int v) {
   return v;
 }
 
+// The two boundary searches of ConstantMedium::hit (hitable.rs:562-566) when the boundary is one sphere `f` (centre, radius): they are
+// the two roots of one quadratic, so it is solved once.  Each search takes the nearer root inside its interval, else the
+// farther one, exactly as Sphere::hit does.
+template <bool STATS>
+__device__ __forceinline__ void medium_sphere_searches(const float* f, int prim, bool on, const RayF& q, Hit& b1, Hit& b2, Counters& cnt) {
+  float h, t_near, t_far;
+  sphere_roots(f, q, h, t_near, t_far);
+  if (STATS) cnt.sphere_tests += on ? 2u : 0u;
+  const float big = 3.402823466e+38f;
+  const bool n1 = (t_near < big) & (t_near > -big), f1 = (t_far < big) & (t_far > -big);
+  const bool v1 = on & (h > 0.0f) & (n1 | f1);
+  b1.t = v1 ? (n1 ? t_near : t_far) : b1.t;
+  b1.prim = v1 ? prim : -1;
+  float t_next = b1.t + 0.0001f;
+  {
+    const int bits = __float_as_int(b1.t);
+    const float up = __int_as_float(bits >= 0 ? bits + 1 : (bits == (int)0x80000000 ? 1 : bits - 1));
+    t_next = t_next > b1.t ? t_next : up;
+  }
+  const bool n2 = (t_near < big) & (t_near > t_next), f2 = (t_far < big) & (t_far > t_next);
+  const bool v2 = on & (h > 0.0f) & (n2 | f2);
+  b2.t = v2 ? (n2 ? t_near : t_far) : b2.t;
+  b2.prim = v2 ? prim : -1;
+}
+
+// The rest of ConstantMedium::hit (hitable.rs:567-596) once the two boundary hits are known: the clamps, the draw, the hit.
+// A hit replaces `best` unless best is nearer.
+template <bool STATS>
+__device__ __forceinline__ void medium_draw(bool on, const Hit& b1, const Hit& b2, const RayF& r, float t_min, float t_max, float density, int ordinal,
+                                            int dprim, const PathRng& rng, Hit& best, Counters& cnt) {
+  float t1 = b1.t, t2 = b2.t;
+  t1 = t1 < t_min ? t_min : t1;
+  t2 = t2 > t_max ? t_max : t2;
+  bool ok = on & (b1.prim >= 0) & (b2.prim >= 0) & !(t1 >= t2);
+  if (STATS) cnt.instance_ops += on;
+  if (__ballot(ok) != 0ull) {  // the draw is only made where some ray crosses the medium
+    t1 = t1 < 0.0f ? 0.0f : t1;
+    const float dlen = sqrtf(dot3(r.d, r.d));
+    const float inside = (t2 - t1) * dlen;
+    const U4 mw = philox4x32_10(rng.pixel, rng.sample, rng.depth, 4096u + (unsigned)ordinal, rng.key0, rng.key1);
+    const float hit_distance = -(1.0f / density) * __logf(u01(mw.x));
+    const float t = t1 + hit_distance / dlen;
+    ok &= (hit_distance < inside) & !(best.t < t);
+    best.t = ok ? t : best.t;
+    best.prim = ok ? dprim : best.prim;
+  }
+}
+
 // ConstantMedium::hit, hitable.rs:560-598 (commented out in the reference), for the K_MEDIUM node `n` at scan[i] and the
-// lanes in `on` (some lane is): the two boundary searches, then the draw.  A hit replaces `best` unless best is nearer.
+// lanes in `on` (some lane is): the two boundary searches, then the draw.
 template <bool STATS>
 __device__ __forceinline__ void medium_node(const DevScene& S, int i, const ScanNode& n, bool on, const RayF& r, float t_min, float t_max,
                                             const PathRng& rng, Hit& best, Counters& cnt) {
@@ -684,26 +734,7 @@ __device__ __forceinline__ void medium_node(const DevScene& S, int i, const Scan
   const int n_boundary = n.b & 0x7fffff;
   const rt_prim bq = load_prim_uniform(S.prims, n.a);
   if (!box6 && n_boundary == 1 && (bq.type & RT_PRIM_TYPE_MASK) == RT_PRIM_SPHERE) {
-    // A sphere as the boundary: the two searches below are the two roots of one quadratic, so it is solved once.
-    // Each search takes the nearer root inside its interval, else the farther one, exactly as Sphere::hit does.
-    float h, t_near, t_far;
-    sphere_roots(bq.f, q, h, t_near, t_far);
-    if (STATS) cnt.sphere_tests += on ? 2u : 0u;
-    const float big = 3.402823466e+38f;
-    const bool n1 = (t_near < big) & (t_near > -big), f1 = (t_far < big) & (t_far > -big);
-    const bool v1 = on & (h > 0.0f) & (n1 | f1);
-    b1.t = v1 ? (n1 ? t_near : t_far) : b1.t;
-    b1.prim = v1 ? n.a : -1;
-    float t_next = b1.t + 0.0001f;
-    {
-      const int bits = __float_as_int(b1.t);
-      const float up = __int_as_float(bits >= 0 ? bits + 1 : (bits == (int)0x80000000 ? 1 : bits - 1));
-      t_next = t_next > b1.t ? t_next : up;
-    }
-    const bool n2 = (t_near < big) & (t_near > t_next), f2 = (t_far < big) & (t_far > t_next);
-    const bool v2 = on & (h > 0.0f) & (n2 | f2);
-    b2.t = v2 ? (n2 ? t_near : t_far) : b2.t;
-    b2.prim = v2 ? n.a : -1;
+    medium_sphere_searches<STATS>(bq.f, n.a, on, q, b1, b2, cnt);
   } else if (box6) {
     box6_two_searches<STATS>(S.scan, i, n.a, on, q, b1, b2, cnt);
   } else {
@@ -719,21 +750,28 @@ __device__ __forceinline__ void medium_node(const DevScene& S, int i, const Scan
     }
     list_test<STATS>(S.prims, n.a, n_boundary, on, q, t_next, 3.402823466e+38f, b2, cnt);
   }
-  float t1 = b1.t, t2 = b2.t;
-  t1 = t1 < t_min ? t_min : t1;
-  t2 = t2 > t_max ? t_max : t2;
-  bool ok = on & (b1.prim >= 0) & (b2.prim >= 0) & !(t1 >= t2);
-  if (STATS) cnt.instance_ops += on;
-  if (__ballot(ok) != 0ull) {  // the draw is only made where some ray crosses the medium
-    t1 = t1 < 0.0f ? 0.0f : t1;
-    const float dlen = sqrtf(dot3(r.d, r.d));
-    const float inside = (t2 - t1) * dlen;
-    const U4 mw = philox4x32_10(rng.pixel, rng.sample, rng.depth, 4096u + (unsigned)ext.a, rng.key0, rng.key1);
-    const float hit_distance = -(1.0f / ext.f[0]) * __logf(u01(mw.x));
-    const float t = t1 + hit_distance / dlen;
-    ok &= (hit_distance < inside) & !(best.t < t);
-    best.t = ok ? t : best.t;
-    best.prim = ok ? ext.b : best.prim;
+  medium_draw<STATS>(on, b1, b2, r, t_min, t_max, ext.f[0], ext.a, ext.b, rng, best, cnt);
+}
+
+// The media of a scene on the stack traversal when each of them is bounded by one sphere in the world frame (the Book-2
+// final scene's mist and smoke): everything ConstantMedium::hit needs of a medium in ONE 64-byte record, so a medium costs the
+// wave one scalar load where the scan array's three records (node, scattering record, boundary primitive) cost it two
+// round trips one after the other.  Record = a ScanNode whose box and y_top are the leaf's, f[0..3] the sphere, f[4] the
+// density, skip the medium's ordinal, a the boundary primitive, b the DevPrim of the scattering point.
+// Same tests in the same order as scan_range over the scan array of such a scene.
+template <bool STATS>
+__device__ __forceinline__ void media_sphere_pass(const DevScene& S, bool act, const RayF& r, float t_min, const PathRng& rng, Hit& best, Counters& cnt) {
+  const Signs sg = ray_signs(r);
+  for (int m = 0; m < S.n_media_sph; ++m) {
+    const ScanNode n = load_node(S.media_sph, m);
+    const bool on = act & slab_test(n, r, sg, t_min, INFINITY, 3.402823466e+38f);
+    if (STATS) cnt.node_tests += act;
+    if (__ballot(on) == 0ull) continue;
+    Hit b1, b2;
+    b1.t = 3.402823466e+38f; b1.prim = -1;
+    b2.t = 3.402823466e+38f; b2.prim = -1;
+    medium_sphere_searches<STATS>(n.f, n.a, on, r, b1, b2, cnt);
+    medium_draw<STATS>(on, b1, b2, r, t_min, INFINITY, n.f[4], n.skip, n.b, rng, best, cnt);
   }
 }
 
@@ -2443,7 +2481,10 @@ __global__ void __launch_bounds__(64, GENERAL < 2 ? RT_STACK_WAVES : 5) render_s
     RT_COUNT(8, 1); RT_COUNT(9, __popcll(__ballot(act)));
     if (__ballot(act) != 0ull) {
       // what is left of world.hit: the ConstantMedium nodes (they draw random numbers)
-      if (GENERAL != 0 && S.n_scan > 0) {
+      if (GENERAL != 0 && S.n_media_sph > 0) {
+        const PathRng rng = {pixel_id, sample, (unsigned)depth, key0, key1};
+        media_sphere_pass<STATS>(S, act, RT_WORLD_RAY(), a_t_min, rng, T.best, cnt);
+      } else if (GENERAL != 0 && S.n_scan > 0) {
         const PathRng rng = {pixel_id, sample, (unsigned)depth, key0, key1};
         scan_range<STATS, true, true, 0>(S, 0, S.n_scan, act, RT_WORLD_RAY(), a_t_min, INFINITY, rng, T.best, cnt);
       }
@@ -2963,7 +3004,10 @@ __global__ void __launch_bounds__(64, GENERAL < 2 ? 5 : 4) render_pool_kernel(De
       int depth = (int)(dp >> 8), pix = (int)(dp & 255u);
       const RayF ray = make_ray(ro, rd);
       // what is left of world.hit: the ConstantMedium nodes (they draw random numbers)
-      if (GENERAL != 0 && S.n_scan > 0) {
+      if (GENERAL != 0 && S.n_media_sph > 0) {
+        const PathRng rng = {pixel_id, sample, (unsigned)depth, key0, key1};
+        media_sphere_pass<STATS>(S, act, ray, a_t_min, rng, h, cnt);
+      } else if (GENERAL != 0 && S.n_scan > 0) {
         const PathRng rng = {pixel_id, sample, (unsigned)depth, key0, key1};
         scan_range<STATS, true, true, 0>(S, 0, S.n_scan, act, ray, a_t_min, INFINITY, rng, h, cnt);
       }
@@ -3321,6 +3365,7 @@ struct rt_ctx {
   void* d_obj_chain;
   void* d_chain_objs;
   void* d_media_bvh;
+  void* d_media_sph;
   void* d_materials;
   void* d_textures;
   void* d_perlins;
@@ -3386,7 +3431,7 @@ int hip_fail(hipError_t e, const char* what) {
   } while (0)
 
 void free_scene(rt_ctx* ctx) {
-  void** ptrs[] = {&ctx->d_scan, &ctx->d_prims, &ctx->d_ref_nodes, &ctx->d_dprims, &ctx->d_leaf_box, &ctx->d_bnodes, &ctx->d_bnodes4, &ctx->d_sub_root_ref, &ctx->d_box6_index, &ctx->d_box6_recs, &ctx->d_prim_rank, &ctx->d_objects, &ctx->d_prim_obj, &ctx->d_obj_chain, &ctx->d_chain_objs, &ctx->d_media_bvh, &ctx->d_materials, &ctx->d_textures, &ctx->d_perlins, &ctx->d_lights};
+  void** ptrs[] = {&ctx->d_scan, &ctx->d_prims, &ctx->d_ref_nodes, &ctx->d_dprims, &ctx->d_leaf_box, &ctx->d_bnodes, &ctx->d_bnodes4, &ctx->d_sub_root_ref, &ctx->d_box6_index, &ctx->d_box6_recs, &ctx->d_prim_rank, &ctx->d_objects, &ctx->d_prim_obj, &ctx->d_obj_chain, &ctx->d_chain_objs, &ctx->d_media_bvh, &ctx->d_media_sph, &ctx->d_materials, &ctx->d_textures, &ctx->d_perlins, &ctx->d_lights};
   for (size_t i = 0; i < sizeof(ptrs) / sizeof(ptrs[0]); ++i) {
     if (*ptrs[i]) (void)hipFree(*ptrs[i]);
     *ptrs[i] = nullptr;
@@ -4670,6 +4715,27 @@ int rt_upload_scene_timed(rt_ctx* ctx, const rt_scene* s, double* upload_ms) {
   if ((rc = upload(&ctx->d_obj_chain, obj_chain.data(), obj_chain.size())) != RT_OK) return rc;
   if ((rc = upload(&ctx->d_chain_objs, chain_objs.data(), chain_objs.size())) != RT_OK) return rc;
   if ((rc = upload(&ctx->d_media_bvh, media_bvh.data(), media_bvh.size())) != RT_OK) return rc;
+  // One self-contained record per medium for media_sphere_pass, when the scene is on the stack traversal and every medium
+  // left in its scan array is bounded by a single sphere in the world frame.
+  std::vector<ScanNode> media_sph;
+  if (stack_mode && !scan.empty()) {
+    bool all = true;
+    for (size_t i = 0; i < scan.size() && all; i = (size_t)scan[i].skip) {
+      const ScanNode& n = scan[i];
+      if (n.skip <= (int)i) { all = false; break; }
+      if (n.kind != K_MEDIUM || (n.b & LIST_IS_BOX6) || (n.b & 0x7fffff) != 1 || (n.b >> 24) != 0 ||
+          (s->prims[n.a].type & RT_PRIM_TYPE_MASK) != RT_PRIM_SPHERE) { all = false; break; }
+      const ScanNode& ext = scan[(size_t)n.skip - 1];
+      ScanNode rec = n;  // the leaf's box, y_top in f[5]
+      for (int c = 0; c < 4; ++c) rec.f[c] = s->prims[n.a].f[c];
+      rec.f[4] = ext.f[0];
+      rec.skip = ext.a;
+      rec.b = ext.b;
+      media_sph.push_back(rec);
+    }
+    if (!all || media_sph.size() > 16) media_sph.clear();
+  }
+  if ((rc = upload(&ctx->d_media_sph, media_sph.data(), media_sph.size())) != RT_OK) return rc;
   B.leaf_box.resize(dprims.size() * 8, 0.0f);
   if ((rc = upload(&ctx->d_leaf_box, B.leaf_box.data(), B.leaf_box.size())) != RT_OK) return rc;
   if ((rc = upload(&ctx->d_bnodes, bnodes.data(), bnodes.size())) != RT_OK) return rc;
@@ -4705,6 +4771,8 @@ int rt_upload_scene_timed(rt_ctx* ctx, const rt_scene* s, double* upload_ms) {
   d.obj_chain = (const int*)ctx->d_obj_chain;
   d.chain_objs = (const int*)ctx->d_chain_objs;
   d.media_bvh = (const MediumBvh*)ctx->d_media_bvh;
+  d.media_sph = (const ScanNode*)ctx->d_media_sph;
+  d.n_media_sph = (int)media_sph.size();
   d.n_media_bvh = (int)media_bvh.size();
   d.stack_mode = stack_mode ? 1 : 0;
   d.stack_depth = stack_mode ? stack_need + 2 : 0;  // what the deepest walk can have in use, and a margin
