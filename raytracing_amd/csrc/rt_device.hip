@@ -2361,8 +2361,14 @@ __global__ void __launch_bounds__(64, (TRAV == TRAV_STACK && GENERAL < 2) ? 6 : 
 #ifndef RT_STACK_LAST_SPP
 #define RT_STACK_LAST_SPP 4  // render_stack_kernel: the last sample chunk of a tile is halved down to parts of this many samples
 #endif
+// Waves per SIMD the register allocator leaves room for.  The LDS a wave holds lets a CU run 20 waves, five per SIMD,
+// whatever the registers allow: the Lambertian build fits 80 registers without spills; the build with all materials
+// needs 96 for that (with 80 it spilled 56 bytes per lane: Book-1 scene 18.8 -> 17.7 ms with 96).
 #ifndef RT_STACK_WAVES
-#define RT_STACK_WAVES 6  // waves per SIMD the register allocator leaves room for in the builds without textures (80 registers: no spills)
+#define RT_STACK_WAVES 6
+#endif
+#ifndef RT_STACK_WAVES_G2
+#define RT_STACK_WAVES_G2 5
 #endif
 // Diagnostic build (-DRT_PHASE_TIMING): shader-clock stamps around the parts of the loop, summed per wave into
 // stats[16..31] by the counting build and printed by rt_render.  No stamp exists in the normal build.
@@ -2374,7 +2380,7 @@ __global__ void __launch_bounds__(64, (TRAV == TRAV_STACK && GENERAL < 2) ? 6 : 
 #define RT_COUNT(k, v) do { } while (0)
 #endif
 template <bool STATS, bool SUMSQ, int GENERAL>
-__global__ void __launch_bounds__(64, GENERAL < 2 ? RT_STACK_WAVES : 5) render_stack_kernel(DevScene S, DevCamera cam, RenderArgs A, float* __restrict__ out_sum,
+__global__ void __launch_bounds__(64, GENERAL < 1 ? RT_STACK_WAVES : (GENERAL < 2 ? 5 : RT_STACK_WAVES_G2)) render_stack_kernel(DevScene S, DevCamera cam, RenderArgs A, float* __restrict__ out_sum,
                                                      float* __restrict__ out_sumsq, unsigned long long* __restrict__ stats, unsigned* __restrict__ queue) {
   // Up to RT_SLOTS work items are open per wave: the one lanes take new paths from (slot f) and earlier ones whose
   // pools are empty and whose last paths are still on their way.  Paths reach depth 50 in scenes with media, and a
