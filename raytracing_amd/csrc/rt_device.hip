@@ -46,6 +46,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <memory>
 #include <thread>
 #include <vector>
 
@@ -3672,14 +3673,21 @@ double geometry_top(const rt_scene* s, int first, int count) {
 // theirs in the object's frame; RotateY and Translate leave heights as they are
 // up to the offset.
 float compute_y_top(const rt_scene* s, int idx, int depth, std::vector<float>* y_top) {
-  // Runs before the tree has been checked: anything out of range is left alone here
-  // and reported by build_scan.
   if (idx < 0 || idx >= s->n_nodes || depth > 130) return -INFINITY;
   const rt_node& n = s->nodes[idx];
   float top = n.bmax[1];
   if (n.left >= 0) {
-    top = std::max(top, compute_y_top(s, n.left, depth + 1, y_top));
-    top = std::max(top, compute_y_top(s, n.right, depth + 1, y_top));
+    if (depth < 4 && s->n_nodes >= (1 << 16)) {
+      // (the tree has been checked by now: no node is reached twice, so the two halves write different elements)
+      float top_left = -INFINITY;
+      std::thread left_half([&]() { top_left = compute_y_top(s, n.left, depth + 1, y_top); });
+      top = std::max(top, compute_y_top(s, n.right, depth + 1, y_top));
+      left_half.join();
+      top = std::max(top, top_left);
+    } else {
+      top = std::max(top, compute_y_top(s, n.left, depth + 1, y_top));
+      top = std::max(top, compute_y_top(s, n.right, depth + 1, y_top));
+    }
   } else if (n.right > 0) {
     const int ref = ~n.left;
     if (ref >= 0 && ref <= s->n_prims - n.right) top = std::max(top, round_up(geometry_top(s, ref, n.right)));
@@ -3856,12 +3864,14 @@ struct BuildNode {
   float top;     // y_top (see slab_core)
   int left, right;
   int ref_node;  // a leaf: the reference node it stands for; -1 for an interior node
+  int n_leaves;  // leaves under the node
 };
 
 struct TreeBuilder {
   const rt_scene* s;
   const std::vector<float>* y_top;
   std::vector<BuildNode> nodes;
+  bool verbose = false;  // RT_VERBOSE: the parts of a large tree's build are timed on stderr
   bool halve_only;  // no heuristic: halve every range as it stands (a balanced tree; the fallback when the other one is too deep)
 
   // the reference leaves under reference node idx, in the reference's depth-first order (objects are leaves here)
@@ -3892,62 +3902,160 @@ struct TreeBuilder {
     b.top = (*y_top)[(size_t)q.ref];
     b.left = b.right = -1;
     b.ref_node = q.ref;
+    b.n_leaves = 1;
     nodes[at] = b;
   }
   static double half_area(const float* lo, const float* hi) {
     const double dx = (double)hi[0] - lo[0], dy = (double)hi[1] - lo[1], dz = (double)hi[2] - lo[2];
     return dx * dy + dy * dz + dz * dx;
   }
+  // Threads for the passes over one large range (the top levels of the tree, where there are fewer ranges than cores).
+  int n_threads = 1;
+  std::vector<LeafRec> scratch;  // as long as the leaf array when a range is large enough for a parallel partition
+  static const int kBins = 16;
+  static const int kSmall = 8;  // ranges up to this many leaves are split by the exact search
+  struct Bins {
+    float blo[3][kBins][3], bhi[3][kBins][3];
+    int cnt[3][kBins];
+    float cmin[3], cmax[3];
+  };
+  // fn(t, lo, hi) for chunk t of [begin, end) cut into n_chunks, chunk 0 on the calling thread
+  template <class F> static void chunks(int begin, int end, int n_chunks, F fn) {
+    const long long n = end - begin;
+    if (n_chunks <= 1) { fn(0, begin, end); return; }
+    std::vector<std::thread> th;
+    for (int t = 1; t < n_chunks; ++t) th.emplace_back([=, &fn]() { fn(t, begin + (int)(n * t / n_chunks), begin + (int)(n * (t + 1) / n_chunks)); });
+    fn(0, begin, begin + (int)(n / n_chunks));
+    for (size_t t = 0; t < th.size(); ++t) th[t].join();
+  }
   // Builds the subtree over leaves[begin, end) (reordered in place) into nodes[base, base + 2 (end - begin) - 1): the
   // left subtree's nodes, the right subtree's, then the root, which is what it returns.  A subtree's slots are known
-  // before it is built, so the two halves of a large range are built by two threads.
+  // before it is built, so the two halves of a large range are built by two threads; the passes over a range of
+  // 2^17 leaves or more are cut into chunks for the threads the halves do not use yet (same tree whatever the number).
   int build(LeafRec* leaves, int begin, int end, size_t base, int depth = 0) {
     const size_t root_at = base + 2 * (size_t)(end - begin) - 2;
     if (end - begin == 1) {
       make_leaf(leaves[begin], root_at);
       return (int)root_at;
     }
-    const int kBins = 16;
     const bool halve = halve_only || depth > 40;  // (a heuristic split can peel off one leaf at a time: bounded here)
-    float cmin[3] = {INFINITY, INFINITY, INFINITY}, cmax[3] = {-INFINITY, -INFINITY, -INFINITY};
-    for (int i = begin; i < end; ++i) {
-      const LeafRec& n = leaves[i];
-      for (int c = 0; c < 3; ++c) {
-        const float ctr = 0.5f * n.bmin[c] + 0.5f * n.bmax[c];
-        if (ctr < cmin[c]) cmin[c] = ctr;
-        if (ctr > cmax[c]) cmax[c] = ctr;
+    if (!halve && end - begin <= kSmall) {
+      // A range of a few leaves: the binned search below costs a node about 1500 operations whatever the range holds
+      // (bins of three axes to clear and to sweep), and nodes over two to eight leaves are six in seven of a tree's
+      // nodes.  Here every split of the range along every axis is priced exactly: leaves in the order of their centres,
+      // boxes of the first k and of the last n - k.
+      const int n = end - begin;
+      int mid_s = begin + 1;
+      if (n > 2) {
+        int order[3][kSmall], best_axis_s = 0, best_k = 1;
+        double best_cost_s = INFINITY;
+        for (int axis = 0; axis < 3; ++axis) {
+          int* o = order[axis];
+          float key[kSmall];
+          for (int i = 0; i < n; ++i) {
+            const float ctr = 0.5f * leaves[begin + i].bmin[axis] + 0.5f * leaves[begin + i].bmax[axis];
+            int j = i;
+            while (j > 0 && key[j - 1] > ctr) { key[j] = key[j - 1]; o[j] = o[j - 1]; --j; }
+            key[j] = ctr;
+            o[j] = i;
+          }
+          double right_area[kSmall];
+          float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+          for (int k = n - 1; k > 0; --k) {
+            const LeafRec& q = leaves[begin + o[k]];
+            for (int c = 0; c < 3; ++c) { if (q.bmin[c] < lo[c]) lo[c] = q.bmin[c]; if (q.bmax[c] > hi[c]) hi[c] = q.bmax[c]; }
+            right_area[k] = half_area(lo, hi);
+          }
+          for (int c = 0; c < 3; ++c) { lo[c] = INFINITY; hi[c] = -INFINITY; }
+          for (int k = 1; k < n; ++k) {
+            const LeafRec& q = leaves[begin + o[k - 1]];
+            for (int c = 0; c < 3; ++c) { if (q.bmin[c] < lo[c]) lo[c] = q.bmin[c]; if (q.bmax[c] > hi[c]) hi[c] = q.bmax[c]; }
+            double cost = half_area(lo, hi) * k + right_area[k] * (n - k);
+            if (!(cost == cost)) cost = 1.0e300;  // a box with an infinite side: still a split
+            if (cost < best_cost_s) { best_cost_s = cost; best_axis_s = axis; best_k = k; }
+          }
+        }
+        LeafRec tmp[kSmall];
+        for (int i = 0; i < n; ++i) tmp[i] = leaves[begin + order[best_axis_s][i]];
+        for (int i = 0; i < n; ++i) leaves[begin + i] = tmp[i];
+        mid_s = begin + best_k;
       }
+      const int l = build(leaves, begin, mid_s, base, depth + 1);
+      const int r = build(leaves, mid_s, end, base + 2 * (size_t)(mid_s - begin) - 1, depth + 1);
+      join_children(root_at, l, r, end - begin);
+      return (int)root_at;
     }
+    int n_chunks = 1;
+    if (end - begin >= (1 << 17) && !scratch.empty()) {
+      n_chunks = depth < 8 ? n_threads >> depth : 1;
+      if (n_chunks < 1) n_chunks = 1;
+    }
+    Bins one;  // (no allocation for the ranges a single thread walks, which are nearly all of them)
+    std::vector<Bins> many(n_chunks > 1 ? (size_t)n_chunks : 0);
+    Bins* part = n_chunks > 1 ? many.data() : &one;
+    chunks(begin, end, n_chunks, [&](int t, int lo, int hi) {
+      Bins& b = part[(size_t)t];
+      for (int c = 0; c < 3; ++c) { b.cmin[c] = INFINITY; b.cmax[c] = -INFINITY; }
+      for (int i = lo; i < hi; ++i) {
+        const LeafRec& n = leaves[i];
+        for (int c = 0; c < 3; ++c) {
+          const float ctr = 0.5f * n.bmin[c] + 0.5f * n.bmax[c];
+          if (ctr < b.cmin[c]) b.cmin[c] = ctr;
+          if (ctr > b.cmax[c]) b.cmax[c] = ctr;
+        }
+      }
+    });
+    float cmin[3] = {INFINITY, INFINITY, INFINITY}, cmax[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int t = 0; t < n_chunks; ++t)
+      for (int c = 0; c < 3; ++c) {
+        if (part[(size_t)t].cmin[c] < cmin[c]) cmin[c] = part[(size_t)t].cmin[c];
+        if (part[(size_t)t].cmax[c] > cmax[c]) cmax[c] = part[(size_t)t].cmax[c];
+      }
     int best_axis = -1, best_split = 0;
     double best_cost = INFINITY;
     if (!halve) {
       // one pass over the leaves fills the bins of all three axes
-      float blo[3][kBins][3], bhi[3][kBins][3];
-      int cnt[3][kBins];
       float scale[3];
       bool usable[3];
       for (int axis = 0; axis < 3; ++axis) {
         const float extent = cmax[axis] - cmin[axis];
         usable[axis] = extent > 0.0f && std::isfinite(extent);
         scale[axis] = usable[axis] ? (float)kBins / extent : 0.0f;
-        for (int k = 0; k < kBins; ++k) {
-          cnt[axis][k] = 0;
-          for (int c = 0; c < 3; ++c) { blo[axis][k][c] = INFINITY; bhi[axis][k][c] = -INFINITY; }
-        }
       }
-      for (int i = begin; i < end; ++i) {
-        const LeafRec& n = leaves[i];
-        for (int axis = 0; axis < 3; ++axis) {
-          if (!usable[axis]) continue;
-          int k = (int)((0.5f * n.bmin[axis] + 0.5f * n.bmax[axis] - cmin[axis]) * scale[axis]);
-          k = k < 0 ? 0 : (k >= kBins ? kBins - 1 : k);
-          ++cnt[axis][k];
-          for (int c = 0; c < 3; ++c) {
-            if (n.bmin[c] < blo[axis][k][c]) blo[axis][k][c] = n.bmin[c];
-            if (n.bmax[c] > bhi[axis][k][c]) bhi[axis][k][c] = n.bmax[c];
+      chunks(begin, end, n_chunks, [&](int t, int lo, int hi) {
+        Bins& b = part[(size_t)t];
+        for (int axis = 0; axis < 3; ++axis)
+          for (int k = 0; k < kBins; ++k) {
+            b.cnt[axis][k] = 0;
+            for (int c = 0; c < 3; ++c) { b.blo[axis][k][c] = INFINITY; b.bhi[axis][k][c] = -INFINITY; }
+          }
+        for (int i = lo; i < hi; ++i) {
+          const LeafRec& n = leaves[i];
+          for (int axis = 0; axis < 3; ++axis) {
+            if (!usable[axis]) continue;
+            int k = (int)((0.5f * n.bmin[axis] + 0.5f * n.bmax[axis] - cmin[axis]) * scale[axis]);
+            k = k < 0 ? 0 : (k >= kBins ? kBins - 1 : k);
+            ++b.cnt[axis][k];
+            for (int c = 0; c < 3; ++c) {
+              if (n.bmin[c] < b.blo[axis][k][c]) b.blo[axis][k][c] = n.bmin[c];
+              if (n.bmax[c] > b.bhi[axis][k][c]) b.bhi[axis][k][c] = n.bmax[c];
+            }
           }
         }
-      }
+      });
+      Bins& all = part[0];
+      for (int t = 1; t < n_chunks; ++t)
+        for (int axis = 0; axis < 3; ++axis)
+          for (int k = 0; k < kBins; ++k) {
+            all.cnt[axis][k] += part[(size_t)t].cnt[axis][k];
+            for (int c = 0; c < 3; ++c) {
+              if (part[(size_t)t].blo[axis][k][c] < all.blo[axis][k][c]) all.blo[axis][k][c] = part[(size_t)t].blo[axis][k][c];
+              if (part[(size_t)t].bhi[axis][k][c] > all.bhi[axis][k][c]) all.bhi[axis][k][c] = part[(size_t)t].bhi[axis][k][c];
+            }
+          }
+      const auto& blo = all.blo;
+      const auto& bhi = all.bhi;
+      const auto& cnt = all.cnt;
       for (int axis = 0; axis < 3; ++axis) {
         if (!usable[axis]) continue;
         // sweep from the right, then from the left
@@ -3982,8 +4090,40 @@ struct TreeBuilder {
         int k = (int)((0.5f * n.bmin[axis] + 0.5f * n.bmax[axis] - base_c) * scale);
         return k < 0 ? 0 : (k >= kBins ? kBins - 1 : k);
       };
-      LeafRec* m = std::stable_partition(leaves + begin, leaves + end, [&](const LeafRec& n) { return bin_of(n) < split; });
-      mid = (int)(m - leaves);
+      if (n_chunks > 1) {
+        // the stable partition in chunks: count, then every chunk moves its leaves to the places the counts give them
+        std::vector<int> n_left((size_t)n_chunks, 0), lo_of((size_t)n_chunks, 0), hi_of((size_t)n_chunks, 0);
+        chunks(begin, end, n_chunks, [&](int t, int lo, int hi) {
+          int c = 0;
+          for (int i = lo; i < hi; ++i) c += bin_of(leaves[i]) < split ? 1 : 0;
+          n_left[(size_t)t] = c;
+          lo_of[(size_t)t] = lo;
+          hi_of[(size_t)t] = hi;
+        });
+        int total_left = 0;
+        for (int t = 0; t < n_chunks; ++t) total_left += n_left[(size_t)t];
+        std::vector<int> at_left((size_t)n_chunks, 0), at_right((size_t)n_chunks, 0);
+        int l_acc = begin, r_acc = begin + total_left;
+        for (int t = 0; t < n_chunks; ++t) {
+          at_left[(size_t)t] = l_acc;
+          at_right[(size_t)t] = r_acc;
+          l_acc += n_left[(size_t)t];
+          r_acc += (hi_of[(size_t)t] - lo_of[(size_t)t]) - n_left[(size_t)t];
+        }
+        LeafRec* tmp = scratch.data();
+        chunks(begin, end, n_chunks, [&](int t, int lo, int hi) {
+          int l = at_left[(size_t)t], r = at_right[(size_t)t];
+          for (int i = lo; i < hi; ++i) {
+            if (bin_of(leaves[i]) < split) tmp[l++] = leaves[i];
+            else tmp[r++] = leaves[i];
+          }
+        });
+        chunks(begin, end, n_chunks, [&](int, int lo, int hi) { std::memcpy(leaves + lo, tmp + lo, (size_t)(hi - lo) * sizeof(LeafRec)); });
+        mid = begin + total_left;
+      } else {
+        LeafRec* m = std::stable_partition(leaves + begin, leaves + end, [&](const LeafRec& n) { return bin_of(n) < split; });
+        mid = (int)(m - leaves);
+      }
       if (mid == begin || mid == end) mid = begin + (end - begin) / 2;
     }
     // (all centres in one point, or nothing to gain: halve the range as it stands)
@@ -3997,6 +4137,10 @@ struct TreeBuilder {
       l = build(leaves, begin, mid, base, depth + 1);
       r = build(leaves, mid, end, right_base, depth + 1);
     }
+    join_children(root_at, l, r, end - begin);
+    return (int)root_at;
+  }
+  void join_children(size_t root_at, int l, int r, int n_leaves) {
     BuildNode b;
     for (int c = 0; c < 3; ++c) {
       b.bmin[c] = nodes[(size_t)l].bmin[c] < nodes[(size_t)r].bmin[c] ? nodes[(size_t)l].bmin[c] : nodes[(size_t)r].bmin[c];
@@ -4006,13 +4150,18 @@ struct TreeBuilder {
     b.left = l;
     b.right = r;
     b.ref_node = -1;
+    b.n_leaves = n_leaves;
     nodes[root_at] = b;
-    return (int)root_at;
   }
   // the device's tree over the reference leaves under reference node idx
   int build_under(int idx) {
+    const auto t0 = std::chrono::steady_clock::now();
     std::vector<int> leaves;
+    auto since = [&](const char* what) {
+      if (verbose && leaves.size() >= 65536) std::fprintf(stderr, "  build_under %-20s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+    };
     collect(idx, &leaves);
+    since("collect");
     if (leaves.empty()) collect(idx, &leaves, true);  // (a world of media only: the tree keeps them so that it has a leaf)
     std::vector<LeafRec> recs(leaves.size());
     for (size_t i = 0; i < leaves.size(); ++i) {
@@ -4020,9 +4169,22 @@ struct TreeBuilder {
       for (int c = 0; c < 3; ++c) { recs[i].bmin[c] = n.bmin[c]; recs[i].bmax[c] = n.bmax[c]; }
       recs[i].ref = leaves[i];
     }
+    since("records");
     const size_t base = nodes.size();
     nodes.resize(base + 2 * recs.size() - 1);
-    return build(recs.data(), 0, (int)recs.size(), base);
+    since("nodes resize");
+    scratch.clear();
+    if (recs.size() >= ((size_t)1 << 17)) {
+      unsigned hw = std::thread::hardware_concurrency();
+      n_threads = hw >= 16 ? 16 : (hw >= 8 ? 8 : (hw >= 4 ? 4 : (hw >= 2 ? 2 : 1)));  // (a power of two: it is halved with every level)
+      if (n_threads > 1) scratch.resize(recs.size());
+    }
+    since("scratch");
+    const int root = build(recs.data(), 0, (int)recs.size(), base);
+    since("build");
+    scratch.clear();
+    scratch.shrink_to_fit();
+    return root;
   }
 };
 
@@ -4033,8 +4195,18 @@ struct Wide4Builder {
   const rt_scene* s;
   TreeBuilder* T;
   std::vector<BNode4> out;
-  std::vector<int> sub_root_ref;  // per object
+  std::vector<int> sub_root_ref_own;          // per object (the top builder's)
+  std::vector<int>* sub_root_ref = nullptr;   // the top builder's, shared by the builders of its parts
+  const std::vector<int>* sub_tree_root = nullptr;  // per object: the built root of an RT_OBJ_BVH's sub-tree (made before the entries: see prebuild)
   const std::vector<int>* box6_index = nullptr;  // per primitive: the six-rect record that starts there, or -1
+  std::vector<int> touched;  // objects whose sub_root_ref is an entry of `out`
+  // Every sub-tree an object leaf will ask for, built before the four-wide entries are: the entries of a large tree are
+  // made by several threads, which then only read the binary nodes.
+  static void prebuild(const rt_scene* s, TreeBuilder* T, std::vector<int>* roots) {
+    roots->assign((size_t)s->n_objects, -1);
+    for (int i = 0; i < s->n_objects; ++i)
+      if (s->objects[i].kind == RT_OBJ_BVH && (s->objects[i].xform & 3) != 0) (*roots)[(size_t)i] = T->build_under(s->objects[i].first);
+  }
   int ref_of_leaf(int ref_node) const {
     const rt_node& c = s->nodes[ref_node];
     if (c.right == 1) return BN2_LEAF | BN2_PRIM | ~c.left;
@@ -4043,21 +4215,35 @@ struct Wide4Builder {
     return BN2_LEAF | ref_node;
   }
   // the reference of built node `idx` (interior: builds its entry) and the stack it needs
-  int ref_of(int idx, int* need) {
+  int ref_of(int idx, int* need, int depth = 0) {
     const BuildNode n = T->nodes[(size_t)idx];
-    if (n.ref_node < 0) return build(idx, need);
+    if (n.ref_node < 0) return build(idx, need, depth);
     *need = 0;
     const rt_node& leaf = s->nodes[n.ref_node];
     if (leaf.right == 0 && s->objects[~leaf.left].kind == RT_OBJ_BVH) {
       int sub = 0;
-      const int sub_root = T->build_under(s->objects[~leaf.left].first);
-      const int r = ref_of(sub_root, &sub);
-      sub_root_ref[(size_t)~leaf.left] = r;
+      const int sub_root = (*sub_tree_root)[(size_t)~leaf.left];
+      const int r = ref_of(sub_root, &sub, 99);
+      (*sub_root_ref)[(size_t)~leaf.left] = r;
+      if (!(r & BN2_LEAF)) touched.push_back(~leaf.left);
       *need = 4 + sub;  // the world ray (three entries) and the marker that switches the lane back to it
     }
     return ref_of_leaf(n.ref_node);
   }
-  int build(int idx, int* need) {
+  // The entries another builder made become entries of this one: their references to each other move by the offset.
+  int adopt(Wide4Builder& part, int part_root) {
+    const int off = (int)out.size();
+    out.insert(out.end(), part.out.begin(), part.out.end());
+    for (size_t i = (size_t)off; i < out.size(); ++i)
+      for (int c = 0; c < 4; ++c)
+        if (out[i].ref[c] != BN4_EMPTY && !(out[i].ref[c] & BN2_LEAF)) out[i].ref[c] += off;
+    for (size_t k = 0; k < part.touched.size(); ++k) {
+      (*sub_root_ref)[(size_t)part.touched[k]] += off;
+      touched.push_back(part.touched[k]);
+    }
+    return part_root + off;
+  }
+  int build(int idx, int* need, int depth = 0) {
     // Start from the two children and, while there is room, open the interior one with the largest box (the one a
     // ray is most likely to enter anyway) into its own two children, keeping the left-to-right order.
     int kids[4] = {T->nodes[(size_t)idx].left, T->nodes[(size_t)idx].right, 0, 0}, n_kids = 2;
@@ -4081,14 +4267,30 @@ struct Wide4Builder {
     out.push_back(BNode4());
     BNode4 b;
     int deepest = 0;
+    // a large interior descendant near the top of a large tree gets a builder and a thread of its own
+    struct Part {
+      Wide4Builder w;
+      int root = 0, need = 0;
+      std::thread th;
+    };
+    std::unique_ptr<Part> parts[4];
     for (int c = 0; c < 4; ++c) {
       if (c < n_kids) {
         const BuildNode k = T->nodes[(size_t)kids[c]];
         b.lox[c] = k.bmin[0]; b.loy[c] = k.bmin[1]; b.loz[c] = k.bmin[2];
         b.hix[c] = k.bmax[0]; b.hiy[c] = k.bmax[1]; b.hiz[c] = k.bmax[2];
         b.top[c] = k.top;
+        if (k.ref_node < 0 && depth < 2 && k.n_leaves >= (1 << 15)) {
+          parts[c].reset(new Part());
+          Part* q = parts[c].get();
+          q->w.s = s; q->w.T = T; q->w.sub_root_ref = sub_root_ref; q->w.sub_tree_root = sub_tree_root; q->w.box6_index = box6_index;
+          q->w.out.reserve((size_t)k.n_leaves * 5 / 8);  // (about half as many entries as leaves; no more than one per interior node)
+          const int kid = kids[c];
+          q->th = std::thread([q, kid, depth]() { q->root = q->w.build(kid, &q->need, depth + 1); });
+          continue;
+        }
         int sub = 0;
-        b.ref[c] = ref_of(kids[c], &sub);
+        b.ref[c] = ref_of(kids[c], &sub, depth + 1);
         if (sub > deepest) deepest = sub;
       } else {
         b.lox[c] = b.loy[c] = b.loz[c] = INFINITY;
@@ -4096,6 +4298,13 @@ struct Wide4Builder {
         b.top[c] = -INFINITY;
         b.ref[c] = BN4_EMPTY;
       }
+    }
+    for (int c = 0; c < 4; ++c)
+      if (parts[c]) parts[c]->th.join();
+    for (int c = 0; c < 4; ++c) {
+      if (!parts[c]) continue;
+      b.ref[c] = adopt(parts[c]->w, parts[c]->root);
+      if (parts[c]->need > deepest) deepest = parts[c]->need;
     }
     out[(size_t)at] = b;
     *need = n_kids - 1 + deepest;
@@ -4545,10 +4754,14 @@ int rt_upload_scene_timed(rt_ctx* ctx, const rt_scene* s, double* upload_ms) {
   TB.s = s;
   TB.y_top = &B.y_top;
   TB.halve_only = false;
+  TB.verbose = verbose;
   Wide4Builder W;
   W.s = s;
   W.T = &TB;
-  W.sub_root_ref.assign((size_t)s->n_objects, 0);
+  W.sub_root_ref_own.assign((size_t)s->n_objects, 0);
+  W.sub_root_ref = &W.sub_root_ref_own;
+  std::vector<int> sub_tree_root;
+  W.sub_tree_root = &sub_tree_root;
   int root_ref = 0, stack_need = 0;
   std::vector<int> box6_index((size_t)s->n_prims, -1);
   std::vector<float> box6_recs;
@@ -4577,12 +4790,18 @@ int rt_upload_scene_timed(rt_ctx* ctx, const rt_scene* s, double* upload_ms) {
     // the world's tree, and the tree of every medium that is bounded by one (walked on its own, after the world's)
     auto build_all = [&]() {
       const int world_root = TB.build_under(0);
+      Wide4Builder::prebuild(s, &TB, &sub_tree_root);
+      std::vector<int> medium_root((size_t)s->n_objects, -1);
+      for (int i = 0; i < s->n_objects; ++i)
+        if (s->objects[i].kind == RT_OBJ_MEDIUM_BVH) medium_root[(size_t)i] = TB.build_under(s->objects[i].first);
       lap("SAH tree");
+      W.touched.clear();
+      W.out.reserve(TB.nodes.size() * 5 / 16);
       root_ref = W.ref_of(world_root, &stack_need);
       for (int i = 0; i < s->n_objects; ++i) {
         if (s->objects[i].kind != RT_OBJ_MEDIUM_BVH) continue;
         int sub = 0;
-        W.sub_root_ref[(size_t)i] = W.ref_of(TB.build_under(s->objects[i].first), &sub);
+        W.sub_root_ref_own[(size_t)i] = W.ref_of(medium_root[(size_t)i], &sub);
         if (sub > stack_need) stack_need = sub;
       }
     };
@@ -4606,7 +4825,9 @@ int rt_upload_scene_timed(rt_ctx* ctx, const rt_scene* s, double* upload_ms) {
   if (stack_mode) {
     // of the scan array only the media's nodes are needed: the world tree's ConstantMedium leaves, in depth-first order
     std::vector<int> world_leaves;
-    TB.collect(0, &world_leaves, true);
+    bool any_medium = false;
+    for (int i = 0; i < s->n_objects; ++i) any_medium |= s->objects[i].kind >= RT_OBJ_MEDIUM;
+    if (any_medium) TB.collect(0, &world_leaves, true);
     for (size_t i = 0; i < world_leaves.size(); ++i) {
       const rt_node& n = s->nodes[world_leaves[i]];
       if (n.right == 0 && s->objects[~n.left].kind >= RT_OBJ_MEDIUM) {
@@ -4746,7 +4967,7 @@ int rt_upload_scene_timed(rt_ctx* ctx, const rt_scene* s, double* upload_ms) {
   if ((rc = upload(&ctx->d_leaf_box, B.leaf_box.data(), B.leaf_box.size())) != RT_OK) return rc;
   if ((rc = upload(&ctx->d_bnodes, bnodes.data(), bnodes.size())) != RT_OK) return rc;
   if ((rc = upload(&ctx->d_bnodes4, W.out.data(), W.out.size())) != RT_OK) return rc;
-  if ((rc = upload(&ctx->d_sub_root_ref, W.sub_root_ref.data(), W.sub_root_ref.size())) != RT_OK) return rc;
+  if ((rc = upload(&ctx->d_sub_root_ref, W.sub_root_ref_own.data(), W.sub_root_ref_own.size())) != RT_OK) return rc;
   if ((rc = upload(&ctx->d_box6_index, box6_index.data(), box6_index.size())) != RT_OK) return rc;
   if ((rc = upload(&ctx->d_box6_recs, box6_recs.data(), box6_recs.size())) != RT_OK) return rc;
   if ((rc = upload(&ctx->d_prim_rank, prim_rank.data(), prim_rank.size())) != RT_OK) return rc;
