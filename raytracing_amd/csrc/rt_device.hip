@@ -1710,6 +1710,9 @@ __device__ __forceinline__ float perlin_turb_wave(const rt_perlin* __restrict__ 
 // Texture::value for the lanes in `need` (the others get an unspecified colour).  Must be called by all 64 lanes: the
 // checker chain is followed per lane, the turbulence of the noise textures is made by the whole wave when few lanes
 // need it (perlin_turb_wave) and by each lane for itself when many do.
+#ifndef RT_TURB_WAVE_MAX
+#define RT_TURB_WAVE_MAX 12  // lanes up to which the wave makes their turbulence one lane after the other (beyond: every lane its own)
+#endif
 __device__ __forceinline__ F3 texture_value_wave(const rt_texture* __restrict__ textures, const rt_perlin* __restrict__ perlins, bool need, int tex, F3 p) {
   F3 col = f3(0, 0, 0);
   bool open = need, noise = false;
@@ -1733,7 +1736,7 @@ __device__ __forceinline__ F3 texture_value_wave(const rt_texture* __restrict__ 
   const unsigned long long m_noise = __ballot(noise);
   if (m_noise != 0ull) {
     float turb = 0.0f;
-    if (__popcll(m_noise) <= 12) {
+    if (__popcll(m_noise) <= RT_TURB_WAVE_MAX) {
       turb = perlin_turb_wave(perlins, noise, perlin_index, p);
     } else if (noise) {
       turb = perlin_turb(perlins + perlin_index, p, 7);

@@ -161,21 +161,18 @@ RotateY::RotateY(HitablePtr h, double angle) : hitable(h) {
   Aabb bbox;
   hasbox = hitable->bounding_box(&bbox);
   if (!hasbox) throw SceneError(RT_ERR_INVALID, "RotateY::new needs a child with a bounding box (hitable.rs:476)");
-  Vec3 mn = scalar(DBL_MAX), mx = scalar(-DBL_MAX);
-  for (int i = 0; i < 2; ++i)
-    for (int j = 0; j < 2; ++j)
-      for (int k = 0; k < 2; ++k) {
-        const double x = i * bbox.max.x + (1.0 - i) * bbox.min.x;
-        const double y = j * bbox.max.y + (1.0 - j) * bbox.min.y;
-        const double z = k * bbox.max.z + (1.0 - k) * bbox.min.z;
-        const double newx = cos_theta * x + sin_theta * z;
-        const double newz = -sin_theta * x + cos_theta * z;
-        const Vec3 tester(newx, y, newz);
-        for (int c = 0; c < 3; ++c) {
-          if (tester[c] > mx[c]) mx.at(c) = tester[c];
-          if (tester[c] < mn[c]) mn.at(c) = tester[c];
-        }
-      }
+  // The box of the rotated child: a turn about y leaves heights alone, so it is the child's y range over the x/z extent
+  // of the box's four rotated vertical edges (the same eight products and sums the source makes for its eight corners).
+  const double edge_x[2] = {bbox.min.x, bbox.max.x}, edge_z[2] = {bbox.min.z, bbox.max.z};
+  double lo_x = DBL_MAX, hi_x = -DBL_MAX, lo_z = DBL_MAX, hi_z = -DBL_MAX;
+  for (int xi = 0; xi < 2; ++xi)
+    for (int zi = 0; zi < 2; ++zi) {
+      const double turned_x = cos_theta * edge_x[xi] + sin_theta * edge_z[zi];
+      const double turned_z = -sin_theta * edge_x[xi] + cos_theta * edge_z[zi];
+      lo_x = std::min(lo_x, turned_x); hi_x = std::max(hi_x, turned_x);
+      lo_z = std::min(lo_z, turned_z); hi_z = std::max(hi_z, turned_z);
+    }
+  const Vec3 mn(lo_x, std::min(bbox.min.y, bbox.max.y), lo_z), mx(hi_x, std::max(bbox.min.y, bbox.max.y), hi_z);
   boxy = Aabb(mn, mx);
 }
 

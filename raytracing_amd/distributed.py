@@ -96,9 +96,6 @@ class TileGather:
         if not self.on:
             return
 
-        def index_of(r):
-            m = torch.from_numpy(shard_tile_mask(nx, ny, r, self.world).reshape(-1))
-            return m.nonzero(as_tuple=False).squeeze(1).to(device)
         # every rank can count every shard's pixels: the dealing is arithmetic on tile numbers
         w = shard_width(nx, self.world)
         import numpy as np
@@ -108,8 +105,16 @@ class TileGather:
         wid = np.minimum(8, nx - 8 * tx)
         self.counts = [int((hgt * wid)[owner == r].sum()) for r in range(self.world)]
         self.pad = max(self.counts)
-        ranks = range(self.world) if self.rank == root else [self.rank]
-        self.index = {r: index_of(r) for r in ranks}
+        if self.rank == root:
+            # the pixel numbers of every rank's tiles from ONE pass over the frame: the owner of every pixel, sorted
+            # stably (so each rank's pixels stay in frame order), cut at the counts
+            owner_px = np.repeat(np.repeat(owner.astype(np.int16), 8, axis=0), 8, axis=1)[:ny, :nx].reshape(-1)
+            order = torch.from_numpy(np.argsort(owner_px, kind="stable"))
+            cuts = np.concatenate(([0], np.cumsum(self.counts)))
+            self.index = {r: order[int(cuts[r]):int(cuts[r + 1])].to(device) for r in range(self.world)}
+        else:
+            m = torch.from_numpy(shard_tile_mask(nx, ny, self.rank, self.world).reshape(-1))
+            self.index = {self.rank: m.nonzero(as_tuple=False).squeeze(1).to(device)}
         self.send = torch.zeros((self.pad, 3), dtype=torch.float32, device=device)
         self.recv = [torch.empty((self.pad, 3), dtype=torch.float32, device=device) for _ in range(self.world)] if self.rank == root else None
 
