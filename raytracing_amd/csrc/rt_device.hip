@@ -2028,7 +2028,10 @@ struct RenderArgs {
 // Dielectric, Isotropic and ConstantMedium; 2 adds checker and noise textures; 3
 // adds light shapes other than one XZRect (lists of shapes, XY/YZ rects, spheres).
 template <bool STATS, bool SUMSQ, int TRAV, int GENERAL>
-__global__ void __launch_bounds__(64, (TRAV == TRAV_STACK && GENERAL < 2) ? 6 : ((GENERAL != 0 || TRAV == TRAV_STACK) ? 5 : RT_RENDER_WAVES_PER_SIMD)) render_kernel(DevScene S, DevCamera cam, RenderArgs A, float* __restrict__ out_sum,
+#ifndef RT_FLAT_G1_WAVES
+#define RT_FLAT_G1_WAVES 5  // (the allocator takes 79 registers by itself, six waves per SIMD; bounding it to 72 for seven was measured: see the experiments)
+#endif
+__global__ void __launch_bounds__(64, (TRAV == TRAV_STACK && GENERAL < 2) ? 6 : ((TRAV == TRAV_FLAT && GENERAL == 1) ? RT_FLAT_G1_WAVES : ((GENERAL != 0 || TRAV == TRAV_STACK) ? 5 : RT_RENDER_WAVES_PER_SIMD))) render_kernel(DevScene S, DevCamera cam, RenderArgs A, float* __restrict__ out_sum,
                                                      float* __restrict__ out_sumsq, unsigned long long* __restrict__ stats, unsigned* __restrict__ queue) {
   // Single-wave workgroups: every wave is on its own, none waits for the slowest
   // wave of a larger group.
