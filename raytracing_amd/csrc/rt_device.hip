@@ -785,6 +785,9 @@ __device__ __forceinline__ void scan_flat_lean(const DevScene& S, int end, bool 
                                                Counters& cnt, const PathRng* rng = nullptr) {
   const bool on_t = STATS ? active : true;  // the caller masks the result with `active` (trace_scan's `got`)
   if (end <= 0) return;
+#ifdef RT_PROBE_CULL
+  const Signs sg_cull = ray_signs(r);
+#endif
   int i = 0;
   do {
     const ScanNode n = load_node(S.scan, i);
@@ -792,6 +795,18 @@ __device__ __forceinline__ void scan_flat_lean(const DevScene& S, int end, bool 
     float cand_t = 0.0f;
     int cand_prim = -1;
     bool take = false;
+#ifdef RT_PROBE_CULL
+    // Diagnostic build: a list's tests are skipped when no lane of the wave passes the list's box (raised to y_top, so
+    // that a Cuboid's lid is inside it).  In the counting build sphere_tests counts the lanes such a skip served.
+    if (kind == K_LIST || kind == K_OBJ_LIST) {
+      const bool in_box = active & slab_test(n, r, sg_cull, t_min, t_max, 3.402823466e+38f);
+      if (__ballot(in_box) == 0ull) {
+        if (STATS) cnt.sphere_tests += active;
+        i = n.skip;
+        continue;
+      }
+    }
+#endif
     if (kind <= K_RECT_YZ) {
       // A single rect: its own t_max test against the running best is the tie rule.
       if (kind == K_RECT_XY) take = rect_test<2, 0, 1>(n.f, r, t_min, best.t, cand_t);
