@@ -299,6 +299,9 @@ def main():
     ap.add_argument("--spheres", type=int, default=1 << 20)
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--lbvh", action="store_true", help="rebuild the world tree on the device (rt_build_lbvh): a separate variant")
+    ap.add_argument("--keep-tree", action="store_true",
+                    help="RT_OPT_KEEP_TREE: the device walks the interior nodes as given (the reference's tree, or with --lbvh the device-built one) "
+                         "collapsed four-wide, instead of the surface-area tree rt_upload_scene builds by default")
     ap.add_argument("--cpu-spp", type=int, default=0, help="also time the f64 oracle at this many spp (8 threads)")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--shard", choices=("tiles", "samples"), default="tiles", help="how ranks split the image when --gpus > 1")
@@ -337,7 +340,12 @@ def main():
         t1 = time.perf_counter()
         flat = r.build_lbvh(flat)
         t_lbvh = time.perf_counter() - t1
+    if args.keep_tree:
+        from raytracing_amd._lib import RT_OPT_KEEP_TREE
+        r.set_option(RT_OPT_KEEP_TREE, 1)
     r.upload_scene(flat)
+    r.upload_scene(flat)  # (the second upload's times: the first pays for the allocator's first pages)
+    upload_ms = r.upload_ms
     p = shard_params(make_params(args.nx, args.ny, args.spp, sky=sky), rank, n_ranks, args.shard)
     best = None
     for _ in range(args.reps):
@@ -431,6 +439,8 @@ def main():
     line = {
         "scene": args.scene, "nx": args.nx, "ny": args.ny, "spp": args.spp, "nodes": flat.n_nodes, "prims": flat.n_prims,
         "tree": "device LBVH (variant)" if args.lbvh else "reference median split", "lbvh_build_s": None if t_lbvh is None else round(t_lbvh, 4),
+        "walked": "the given interior, collapsed four-wide (RT_OPT_KEEP_TREE)" if args.keep_tree else "rt_upload_scene's own surface-area tree over the given leaves",
+        "upload_ms": {"host_build": round(upload_ms[0], 2), "device_copies": round(upload_ms[1], 2)},
         "build_s": round(t_build, 2), "kernel_ms": round(prod_ms, 3), "counting_kernel_ms": round(best.kernel_ms, 3),
         "n_gpus": n_ranks, "sharding": "single GPU" if n_ranks == 1 else ("REHEARSAL on one GPU, " if args.rehearse_on_one_gpu else "") + args.shard,
         "ms_per_image": round(t_ms, 3),

@@ -313,6 +313,12 @@ int rt_destroy(rt_ctx* ctx);
  *     1..64, default 16): finished walks that make it hand them over and take new rays;
  *     RT_OPT_HUNGRY_LANES (RT_HUNGRY_LANES; 1..64, default 8): idle lanes, with no ray
  *     waiting, that make it run a waiting batch of any size.
+ *   RT_OPT_KEEP_TREE (RT_KEEP_TREE; 0 or 1, default 0; read by rt_upload_scene): with 1,
+ *     scenes on the per-lane stack traversal walk the interior nodes AS GIVEN (the
+ *     reference's own BvhNode::new tree, src/bvh.rs:105-147, or the one rt_build_lbvh
+ *     made on the device), collapsed to four-wide entries, instead of the
+ *     surface-area tree rt_upload_scene builds over the leaves by default: a cheaper
+ *     upload, slower walks.  Nearest hits are the same either way.
  * None of these changes which paths are traced or what they return: a pixel's sum
  * changes at most in the order of its fp32 additions. */
 #define RT_OPT_FIXED_ORDER 1
@@ -328,6 +334,7 @@ int rt_destroy(rt_ctx* ctx);
 #define RT_OPT_REFILL_LANES 11
 #define RT_OPT_TEX_BATCH 12
 #define RT_OPT_HUNGRY_LANES 13
+#define RT_OPT_KEEP_TREE 14
 int rt_set_option(rt_ctx* ctx, int option, int value);
 int rt_get_option(const rt_ctx* ctx, int option, int* value_out);
 

@@ -30,7 +30,7 @@ RT_MULTI_NO_RCCL = 1
 RT_MULTI_FORCE_RCCL = 2
 (RT_OPT_FIXED_ORDER, RT_OPT_READY_LANES, RT_OPT_HOLD_LANES, RT_OPT_STACK_LDS_ENTRIES, RT_OPT_WAVES_PER_CU,
  RT_OPT_ITEM_ROUNDS, RT_OPT_MIN_CHUNK_SPP, RT_OPT_LAST_CHUNK_SPP, RT_OPT_POOL_SLOTS, RT_OPT_SHADE_BATCH,
- RT_OPT_REFILL_LANES, RT_OPT_TEX_BATCH, RT_OPT_HUNGRY_LANES) = range(1, 14)
+ RT_OPT_REFILL_LANES, RT_OPT_TEX_BATCH, RT_OPT_HUNGRY_LANES, RT_OPT_KEEP_TREE) = range(1, 15)
 
 
 class rt_node(C.Structure):

@@ -151,6 +151,7 @@ struct DevScene {
   const rt_node* ref_nodes;  // the node array as it was passed in (trace64_kernel walks it the reference's way)
   int n_ref_nodes;
   int stack_mode;
+  int no_prune;     // some geometry lies outside the boxes above it (a sphere of negative radius in a list): boxes are never skipped by distance
   int stack_depth;  // entries per lane of the traversal stack that the deepest walk can need
   int stack_lds;    // of which this many live in LDS
   rt_light light;          // the first shape (the only one in the reference's own case: one XZRect)
@@ -864,7 +865,7 @@ __device__ __forceinline__ void scan_range(const DevScene& S, int begin, int end
     // Hierarchical arrays also skip a box entered beyond the best hit so far.  A flat
     // array does not: its leaves are few, and a Cuboid's top face lies 0.01 above the
     // cuboid's own box (hitable.rs:398-399), where that shortcut is not exact.
-    const bool on = DEFER ? act : (act & slab_test(n, r, sg, t_min, t_max, FLAT ? 3.402823466e+38f : best.t));
+    const bool on = DEFER ? act : (act & slab_test(n, r, sg, t_min, t_max, (FLAT || S.no_prune) ? 3.402823466e+38f : best.t));
     if (STATS && !DEFER) cnt.node_tests += act;
     // Without box tests every lane of the scan has the same `on`, the caller's `active`, and the caller masks the result
     // with it again (trace_scan's `got`): the primitive tests then run unmasked, which saves a mask operation per test.
@@ -1016,6 +1017,7 @@ struct LaneStackT {
   lds_u32* lds;  // this lane's column: entry `at` is the pair lds[at * 128] (reference), lds[at * 128 + 64] (distance key)
   int n_lds;     // entries in LDS
   glb_u32* ovf;  // this lane's column of the wave's overflow region, same layout (OVF only)
+  float prune_scale;  // 1, or +inf for a scene walked without skipping boxes by distance (DevScene::no_prune): the best hit so far times this is what a box's entry distance is compared with
   __device__ __forceinline__ void put(int at, unsigned ref, unsigned key) {
     if (!OVF || at < n_lds) { lds[at * 128] = ref; lds[at * 128 + 64] = key; }
     else { ovf[(at - n_lds) * 128] = ref; ovf[(at - n_lds) * 128 + 64] = key; }
@@ -1057,7 +1059,9 @@ __device__ __forceinline__ int trav_enter(const DevScene& S, int ref, int box, c
 // test its boxes and go to the nearest descendant the ray enters, pushing the others farthest first.  Returns false
 // when the walk has ended.  (Leaves, single primitives included, are left to trav_leaf: the wave runs that code for
 // many lanes at once, which was measured faster than testing a primitive where a lane meets it.)
-template <bool STATS, class STK>
+// CHECKED: the build also serves scenes that must be walked without skipping boxes by distance (stk.prune_scale = +inf):
+// only the most general render build and the nearest-hit query pay for the multiplication.
+template <bool STATS, bool CHECKED, class STK>
 __device__ __forceinline__ bool trav_step_impl(const DevScene& S, STK& stk, Trav& T, float t_min, float t_max, Counters& cnt) {
   if (T.cur == TRAV_POP) {
     // Entries wait on the stack with their pruning distance (the sort key of the step that pushed them: the distance
@@ -1077,7 +1081,7 @@ __device__ __forceinline__ bool trav_step_impl(const DevScene& S, STK& stk, Trav
     }
     // (no loop: a lane whose entry is pruned pops the next one in its next trip; looping here, or looking at two
     // entries at once, was measured slower)
-    if (__uint_as_float(key & ~3u) > T.best.t) return true;
+    if (__uint_as_float(key & ~3u) > (CHECKED ? T.best.t * stk.prune_scale : T.best.t)) return true;
     T.cur = (int)x;
   }
   const int cur = T.cur;
@@ -1087,10 +1091,14 @@ __device__ __forceinline__ bool trav_step_impl(const DevScene& S, STK& stk, Trav
   const float4 lox = rec[0], loy = rec[1], loz = rec[2], hix = rec[3], hiy = rec[4], hiz = rec[5], refs_f = rec[6], top = rec[7];
   const Signs sg = ray_signs(T.r);
   float t0, t1, t2, t3;
-  const bool h0 = slab_core(lox.x, loy.x, loz.x, hix.x, hiy.x, hiz.x, top.x, T.r, sg, t_min, t_max, T.best.t, t0);
-  const bool h1 = slab_core(lox.y, loy.y, loz.y, hix.y, hiy.y, hiz.y, top.y, T.r, sg, t_min, t_max, T.best.t, t1);
-  const bool h2 = slab_core(lox.z, loy.z, loz.z, hix.z, hiy.z, hiz.z, top.z, T.r, sg, t_min, t_max, T.best.t, t2);
-  const bool h3 = slab_core(lox.w, loy.w, loz.w, hix.w, hiy.w, hiz.w, top.w, T.r, sg, t_min, t_max, T.best.t, t3);
+  // (Skipping a box entered beyond the best hit so far takes for granted that what lies under a box lies inside it.  A
+  // sphere of negative radius has an inverted box of its own, hitable.rs:86-91, so the boxes above a list that holds
+  // one do not contain it: scenes with such a sphere are walked without that shortcut, as the reference walks every scene.)
+  const float prune_t = CHECKED ? T.best.t * stk.prune_scale : T.best.t;
+  const bool h0 = slab_core(lox.x, loy.x, loz.x, hix.x, hiy.x, hiz.x, top.x, T.r, sg, t_min, t_max, prune_t, t0);
+  const bool h1 = slab_core(lox.y, loy.y, loz.y, hix.y, hiy.y, hiz.y, top.y, T.r, sg, t_min, t_max, prune_t, t1);
+  const bool h2 = slab_core(lox.z, loy.z, loz.z, hix.z, hiy.z, hiz.z, top.z, T.r, sg, t_min, t_max, prune_t, t2);
+  const bool h3 = slab_core(lox.w, loy.w, loz.w, hix.w, hiy.w, hiz.w, top.w, T.r, sg, t_min, t_max, prune_t, t3);
   const int r0 = __float_as_int(refs_f.x), r1 = __float_as_int(refs_f.y), r2 = __float_as_int(refs_f.z), r3 = __float_as_int(refs_f.w);
   if (STATS) cnt.node_tests += 2u + (r2 != BN4_EMPTY) + (r3 != BN4_EMPTY);  // (empty slots are the last ones)
   // Order by entry distance: the distance (not negative, so its bits order like an integer) with its two lowest bits
@@ -1119,18 +1127,19 @@ __device__ __forceinline__ bool trav_step_impl(const DevScene& S, STK& stk, Trav
 // A stack with a global part decides at every access which part an entry lives in, a branch around each of a step's
 // five accesses.  Walks seldom leave the LDS part, so the wave first asks whether any of its stepping lanes could (a
 // step pops one entry or pushes three at most): if none can, the step runs on a view of the stack that has no global part.
-template <bool STATS, class STK>
+template <bool STATS, bool CHECKED = true, class STK>
 __device__ __forceinline__ bool trav_step(const DevScene& S, STK& stk, Trav& T, float t_min, float t_max, Counters& cnt) {
   if (STK::kOvf) {
     if (__ballot(T.sp + 3 > stk.n_lds) == 0ull) {
       LaneStackT<false> in_lds;
       in_lds.lds = stk.lds;
       in_lds.n_lds = stk.n_lds;
+      in_lds.prune_scale = stk.prune_scale;
       in_lds.ovf = nullptr;
-      return trav_step_impl<STATS>(S, in_lds, T, t_min, t_max, cnt);
+      return trav_step_impl<STATS, CHECKED>(S, in_lds, T, t_min, t_max, cnt);
     }
   }
-  return trav_step_impl<STATS>(S, stk, T, t_min, t_max, cnt);
+  return trav_step_impl<STATS, CHECKED>(S, stk, T, t_min, t_max, cnt);
 }
 
 // The leaf a lane holds (its box has been passed): a primitive list in the current frame, or an object:
@@ -1208,6 +1217,7 @@ __device__ __forceinline__ void trace_stack(const DevScene& S, unsigned* __restr
   LaneStackT<false> stk;
   stk.lds = (lds_u32*)stk_lds;
   stk.n_lds = S.stack_lds;
+  stk.prune_scale = S.no_prune ? INFINITY : 1.0f;
   stk.ovf = nullptr;
   trace_tree<STATS>(S, stk, S.root_ref, 0, w, t_min, t_max, best, cnt);
 }
@@ -2415,6 +2425,11 @@ __global__ void __launch_bounds__(64, GENERAL < 1 ? RT_STACK_WAVES : (GENERAL < 
   LaneStackT<true> stk;
   stk.lds = (lds_u32*)((unsigned*)prim_lds + (threadIdx.x & 63));
   stk.n_lds = A.stack_lds;
+  {
+    unsigned ps = S.no_prune ? 0x7f800000u : 0x3f800000u;  // +inf or 1.0f
+    asm volatile("" : "+s"(ps));  // (a register of its own: see the copies of the kernel's arguments below)
+    stk.prune_scale = __uint_as_float(ps);
+  }
   stk.ovf = (glb_u32*)(A.stack_ovf + (size_t)blockIdx.x * (size_t)(S.stack_depth - A.stack_lds) * 128 + (threadIdx.x & 63));
   const int lane = threadIdx.x & 63;
   __shared__ float cam_lds[20];
@@ -2731,7 +2746,7 @@ __global__ void __launch_bounds__(64, GENERAL < 1 ? RT_STACK_WAVES : (GENERAL < 
     for (;;) {
       RT_COUNT(10, 1); RT_COUNT(11, __popcll(__ballot(trav)));
       // one step for every lane that has one to make; a lane holding a list or instance leaf waits for the leaf code below
-      if (trav & !trav_holds_leaf(T.cur)) trav = trav_step<STATS>(S, stk, T, a_t_min, INFINITY, cnt);
+      if (trav & !trav_holds_leaf(T.cur)) trav = trav_step<STATS, GENERAL == 3>(S, stk, T, a_t_min, INFINITY, cnt);
       RT_STAMP(6);  // step
       const bool hold = trav & trav_holds_leaf(T.cur);
       const unsigned long long m_trav = __ballot(trav), m_hold = __ballot(hold);
@@ -2820,6 +2835,11 @@ __global__ void __launch_bounds__(64, GENERAL < 2 ? 5 : 4) render_pool_kernel(De
   LaneStackT<true> stk;
   stk.lds = (lds_u32*)((unsigned*)prim_lds + lane);
   stk.n_lds = A.stack_lds;
+  {
+    unsigned ps = S.no_prune ? 0x7f800000u : 0x3f800000u;  // +inf or 1.0f
+    asm volatile("" : "+s"(ps));  // (a register of its own: see the copies of the kernel's arguments below)
+    stk.prune_scale = __uint_as_float(ps);
+  }
   stk.ovf = (glb_u32*)(A.stack_ovf + (size_t)blockIdx.x * (size_t)(S.stack_depth - A.stack_lds) * 128 + lane);
   const int P = A.pool_slots;
   glb_char* const recs = (glb_char*)A.pool_mem + (size_t)blockIdx.x * (size_t)P * sizeof(PoolRec);  // this wave's records
@@ -3270,7 +3290,7 @@ __global__ void __launch_bounds__(64, GENERAL < 2 ? 5 : 4) render_pool_kernel(De
       if (ray_n == 0 && __popcll(m_trav1) <= 64 - a_hungry && (shade_n + spawnable > 0 || tex_n > 0)) break;
       RT_COUNT(10, 1); RT_COUNT(11, __popcll(m_trav1));
       // one step for every lane that has one to make; a lane holding a list or instance leaf waits for the leaf code below
-      if (trav & !trav_holds_leaf(T.cur)) trav = trav_step<STATS>(S, stk, T, a_t_min, INFINITY, cnt);
+      if (trav & !trav_holds_leaf(T.cur)) trav = trav_step<STATS, GENERAL == 3>(S, stk, T, a_t_min, INFINITY, cnt);
       RT_STAMP(6);  // step
       const bool hold = trav & trav_holds_leaf(T.cur);
       const unsigned long long m_trav = __ballot(trav), m_hold = __ballot(hold);
@@ -3371,7 +3391,7 @@ static __device__ __align__(256) unsigned char scratch[RT_NOALLOC_SCRATCH_BYTES]
 // ---------------------------------------------------------------------------
 // Host side of the ABI
 // ---------------------------------------------------------------------------
-#define RT_OPT_COUNT 14  // RT_OPT_* of rt_abi.h are 1..13
+#define RT_OPT_COUNT 15  // RT_OPT_* of rt_abi.h are 1..14
 struct rt_ctx {
   int device;
   bool has_scene;
@@ -3441,6 +3461,7 @@ const OptSpec kOptSpec[RT_OPT_COUNT] = {
     {1, 64, 16, "RT_REFILL_LANES"},       // RT_OPT_REFILL_LANES
     {1, 64, 24, "RT_TEX_BATCH"},          // RT_OPT_TEX_BATCH
     {1, 64, 8, "RT_HUNGRY_LANES"},        // RT_OPT_HUNGRY_LANES
+    {0, 1, 0, "RT_KEEP_TREE"},            // RT_OPT_KEEP_TREE
 };
 int clamp_opt(int option, int value) {
   const OptSpec& o = kOptSpec[option];
@@ -4174,8 +4195,37 @@ struct TreeBuilder {
     b.n_leaves = n_leaves;
     nodes[root_at] = b;
   }
+  // RT_OPT_KEEP_TREE: the interior as it was given (the reference's own BvhNode::new tree, or rt_build_lbvh's) instead of
+  // one built here.  Same leaves and the same rules as collect(): a BvhNode item without a frame change joins its parent's
+  // tree, a ConstantMedium is no leaf.  Returns the root's index in `nodes`, or -1 when there is no leaf under idx.
+  bool keep_given = false;
+  int mirror(int idx) {
+    const rt_node& n = s->nodes[idx];
+    if (n.left < 0) {
+      if (n.right == 0 && s->objects[~n.left].kind == RT_OBJ_BVH && (s->objects[~n.left].xform & 3) == 0) return mirror(s->objects[~n.left].first);
+      if (n.right == 0 && s->objects[~n.left].kind >= RT_OBJ_MEDIUM) return -1;
+      LeafRec q;
+      for (int c = 0; c < 3; ++c) { q.bmin[c] = n.bmin[c]; q.bmax[c] = n.bmax[c]; }
+      q.ref = idx;
+      nodes.push_back(BuildNode());
+      make_leaf(q, nodes.size() - 1);
+      return (int)nodes.size() - 1;
+    }
+    const int l = mirror(n.left), r = mirror(n.right);
+    if (l < 0) return r;
+    if (r < 0) return l;
+    nodes.push_back(BuildNode());
+    // (the union of the children's boxes, as the reference's surrounding_box makes it: equal to the given box where the
+    // given tree is the reference's, and never larger)
+    join_children(nodes.size() - 1, l, r, nodes[(size_t)l].n_leaves + nodes[(size_t)r].n_leaves);
+    return (int)nodes.size() - 1;
+  }
   // the device's tree over the reference leaves under reference node idx
   int build_under(int idx) {
+    if (keep_given && !halve_only) {
+      const int root = mirror(idx);
+      if (root >= 0) return root;
+    }
     const auto t0 = std::chrono::steady_clock::now();
     std::vector<int> leaves;
     auto since = [&](const char* what) {
@@ -4776,6 +4826,7 @@ int rt_upload_scene_timed(rt_ctx* ctx, const rt_scene* s, double* upload_ms) {
   TB.y_top = &B.y_top;
   TB.halve_only = false;
   TB.verbose = verbose;
+  TB.keep_given = ctx->opt[RT_OPT_KEEP_TREE] != 0;
   Wide4Builder W;
   W.s = s;
   W.T = &TB;
@@ -5023,6 +5074,9 @@ int rt_upload_scene_timed(rt_ctx* ctx, const rt_scene* s, double* upload_ms) {
   d.n_media_sph = (int)media_sph.size();
   d.n_media_bvh = (int)media_bvh.size();
   d.stack_mode = stack_mode ? 1 : 0;
+  d.no_prune = 0;
+  for (int i = 0; i < s->n_prims; ++i)
+    if ((s->prims[i].type & RT_PRIM_TYPE_MASK) == RT_PRIM_SPHERE && s->prims[i].f[3] < 0.0f) d.no_prune = 1;
   d.stack_depth = stack_mode ? stack_need + 2 : 0;  // what the deepest walk can have in use, and a margin
   d.stack_lds = d.stack_depth;  // (the trace kernel's; the render kernel's LDS part is set per launch)
   lap("records, copies to the device");
@@ -5048,7 +5102,7 @@ int rt_upload_scene_timed(rt_ctx* ctx, const rt_scene* s, double* upload_ms) {
   d.light_general = (s->n_lights > 1 || (s->n_lights == 1 && s->lights[0].type != RT_LIGHT_XZ_RECT)) ? 1 : 0;
   // (the general light code is compiled into build 3 only, so that the other builds keep their registers; so is the code
   // for primitives inside more than one object and for media bounded by a sub-tree)
-  ctx->general = (d.light_general || has_chains || d.n_media_bvh > 0) ? 3 : textured ? 2 : ((!B.media.empty() || (mat_mask & ~((1 << RT_MAT_LAMBERTIAN) | (1 << RT_MAT_DIFFUSE_LIGHT))) != 0) ? 1 : 0);
+  ctx->general = (d.light_general || has_chains || d.n_media_bvh > 0 || (d.no_prune && stack_mode)) ? 3 : textured ? 2 : ((!B.media.empty() || (mat_mask & ~((1 << RT_MAT_LAMBERTIAN) | (1 << RT_MAT_DIFFUSE_LIGHT))) != 0) ? 1 : 0);
   ctx->has_scene = true;
   const auto t_end = std::chrono::steady_clock::now();
   ctx->upload_ms[0] = std::chrono::duration<double, std::milli>(t_built - t_begin).count();

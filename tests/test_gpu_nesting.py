@@ -170,3 +170,59 @@ def test_a_medium_inside_another_hitable_is_refused():
         with pytest.raises(RtError) as e:
             sc.flatten(S.HitableList.new([S.Translate.new(fog, S.vec3(1.0, 0.0, 0.0)), S.Sphere.new(S.vec3(3, 0, 0), 1.0, grey)]))
         assert e.value.code == _lib.RT_ERR_UNSUPPORTED
+
+
+def test_keep_tree_option_walks_the_given_interior(gpu, orc):
+    """RT_OPT_KEEP_TREE: the device collapses the interior nodes it is given instead of building its own over the leaves.
+    Any tree over the same leaves gives the same nearest hits, so the traces stay bit-exact against the oracle (which walks
+    the given tree) for the flattener's tree, for nested objects, and for the tree rt_build_lbvh makes on the device; the
+    number of box tests shows that another tree is being walked."""
+    from raytracing_amd._lib import RT_OPT_KEEP_TREE
+    rng = np.random.RandomState(77)
+    with Scene(5) as sc:
+        mats = [S.Lambertian.new_from_color(S.vec3(0.6, 0.5, 0.4))]
+        world = S.HitableList.new([_random_nested(rng, mats, 2) for _ in range(150)])
+        flat = sc.flatten(world)
+    p = make_params(64, 48, 4, seed=3)
+    cam = S.Camera.new(S.vec3(0.0, 4.0, 30.0), S.vec3(0.0, 0.0, 0.0), S.vec3(0.0, 1.0, 0.0), 40.0, 64.0 / 48.0, 0.0, 10.0)
+    gpu.upload_scene(flat)
+    _, st_own = gpu.render(cam, p, want_stats=True)
+    gpu.set_option(RT_OPT_KEEP_TREE, 1)
+    try:
+        prim = _check_trace(gpu, orc, flat, rng, m=12000)
+        assert (prim >= 0).sum() > 500
+        _, st_kept = gpu.render(cam, p, want_stats=True)
+        assert (st_kept.rays, st_kept.hits) == (st_own.rays, st_own.hits)
+        assert st_kept.node_tests != st_own.node_tests
+        # a world of plain spheres through the device-built linear BVH, kept
+        from test_gpu_trace import _lbvh_scene
+        sc2, flat2 = _lbvh_scene(3000, 11)
+        lb = gpu.build_lbvh(flat2)
+        gpu.upload_scene(lb)
+        o, d = _rays(rng, 12000, lo=-30.0, hi=30.0, aim=10.0)
+        prim_l, t_l = gpu.trace_closest(o, d)
+        oprim, ot = orc.trace_closest(lb, o, d, mode=orc.ORC_F32_FUSED)  # the oracle walks the same device-built tree
+        assert (prim_l >= 0).mean() > 0.02
+        assert np.array_equal(prim_l, oprim) and np.array_equal(t_l, ot.astype(np.float32))
+    finally:
+        gpu.set_option(RT_OPT_KEEP_TREE, 0)
+
+
+def test_sphere_of_negative_radius_in_a_wrapped_list(gpu, orc):
+    """A sphere of negative radius (the hollow-sphere trick) has an inverted box of its own (hitable.rs:86-91), so the boxes
+    above a list that holds one do not contain it and a ray can hit it before it enters them.  The reference walks every
+    box the ray passes whatever has been found already, so it finds that hit; the device must not skip such a box for
+    lying beyond its best hit so far."""
+    rng = np.random.RandomState(5)
+    with Scene(9) as sc:
+        m = S.Lambertian.new_from_color(S.vec3(0.5, 0.5, 0.5))
+        items = [S.Sphere.new(S.vec3(*rng.uniform(-14, 14, 3)), float(rng.uniform(0.3, 1.5)), m) for _ in range(120)]
+        for k in range(12):
+            c = rng.uniform(-8, 8, 3)
+            inner = S.HitableList.new([S.Sphere.new(S.vec3(*c), -float(rng.uniform(1.0, 2.5)), m),
+                                       S.Sphere.new(S.vec3(*(c + rng.uniform(-3, 3, 3))), 0.4, m)])
+            items.append(S.Translate.new(S.RotateY.new(inner, float(rng.uniform(-60, 60))), S.vec3(*rng.uniform(-1, 1, 3))))
+        flat = sc.flatten(S.HitableList.new(items))
+    prim = _check_trace(gpu, orc, flat, rng, m=30000)
+    hollow = [k for k in range(flat.n_prims) if flat.prims[k].f[3] < 0.0]
+    assert len(hollow) == 12 and np.isin(prim, hollow).sum() > 100

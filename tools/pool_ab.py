@@ -21,7 +21,7 @@ from bench_scenes import build  # noqa: E402
 NAMES = {"pool": _lib.RT_OPT_POOL_SLOTS, "shade": _lib.RT_OPT_SHADE_BATCH, "refill": _lib.RT_OPT_REFILL_LANES, "tex": _lib.RT_OPT_TEX_BATCH,
          "hungry": _lib.RT_OPT_HUNGRY_LANES, "hold": _lib.RT_OPT_HOLD_LANES, "ready": _lib.RT_OPT_READY_LANES, "lds": _lib.RT_OPT_STACK_LDS_ENTRIES,
          "waves": _lib.RT_OPT_WAVES_PER_CU, "fixed": _lib.RT_OPT_FIXED_ORDER, "rounds": _lib.RT_OPT_ITEM_ROUNDS, "minspp": _lib.RT_OPT_MIN_CHUNK_SPP,
-         "lastspp": _lib.RT_OPT_LAST_CHUNK_SPP}
+         "lastspp": _lib.RT_OPT_LAST_CHUNK_SPP, "keep": _lib.RT_OPT_KEEP_TREE}
 
 
 def main():
@@ -40,7 +40,12 @@ def main():
         flat = sc.flatten(world)
     r = Renderer(0)
     r.upload_scene(flat)
-    defaults = {k: r.get_option(v) for k, v in NAMES.items()}
+    defaults = {}
+    for k, v in NAMES.items():
+        try:
+            defaults[k] = r.get_option(v)
+        except Exception:  # (an older build of the library that does not have this option)
+            pass
     p = make_params(nx, ny, spp, sky=sky)
     buf = torch.empty(ny * nx * 3, dtype=torch.float32, device=dev)
     stream = torch.cuda.current_stream(dev)
