@@ -131,7 +131,8 @@ struct DevScene {
   const struct BNode* bnodes;
   const struct BNode4* bnodes4;
   int root_ref;            // the world tree's root as a reference
-  const int* sub_root_ref;  // per object: the reference of an RT_OBJ_BVH's sub-tree root
+  const int* sub_root_ref;  // per object, two values: the reference of an RT_OBJ_BVH's sub-tree root, and the node whose box is the root's own
+  int root_box;             // the same node for the world's tree
   const int* box6_index;   // per primitive: >= 0 where a list of six rects in Cuboid::new's order starts, the index of its record
   const float4* box6_recs; // 5 float4 per record: the 18 floats of box6_test, padded
   const int* prim_rank;  // per primitive: depth-first rank of its leaf
@@ -1181,7 +1182,7 @@ __device__ __forceinline__ void trav_leaf(const DevScene& S, STK& stk, Trav& T, 
     stk.put(T.sp + 3, STACK_RESTORE, 0u);
     T.sp += 4;
     T.r = q;
-    T.cur = trav_enter<STATS>(S, S.sub_root_ref[ref], ob.first, T.r, t_min, t_max, cnt);
+    T.cur = trav_enter<STATS>(S, S.sub_root_ref[2 * ref], S.sub_root_ref[2 * ref + 1], T.r, t_min, t_max, cnt);
   }
 }
 
@@ -1219,7 +1220,7 @@ __device__ __forceinline__ void trace_stack(const DevScene& S, unsigned* __restr
   stk.n_lds = S.stack_lds;
   stk.prune_scale = S.no_prune ? INFINITY : 1.0f;
   stk.ovf = nullptr;
-  trace_tree<STATS>(S, stk, S.root_ref, 0, w, t_min, t_max, best, cnt);
+  trace_tree<STATS>(S, stk, S.root_ref, S.root_box, w, t_min, t_max, best, cnt);
 }
 
 // ConstantMedium::hit (hitable.rs:560-598, commented out in the reference) for the media whose boundary is a sub-tree:
@@ -1240,15 +1241,15 @@ __device__ __forceinline__ void media_bvh_pass(const DevScene& S, STK& stk, bool
     Hit b1, b2;
     b1.t = big; b1.prim = -1;
     b2.t = big; b2.prim = -1;
-    const int root = S.sub_root_ref[mb.object];
-    if (on) trace_tree<STATS>(S, stk, root, ob.first, q, -big, big, b1, cnt);
+    const int root = S.sub_root_ref[2 * mb.object], root_box = S.sub_root_ref[2 * mb.object + 1];
+    if (on) trace_tree<STATS>(S, stk, root, root_box, q, -big, big, b1, cnt);
     float t_next = b1.t + 0.0001f;
     {
       const int bits = __float_as_int(b1.t);
       const float up = __int_as_float(bits >= 0 ? bits + 1 : (bits == (int)0x80000000 ? 1 : bits - 1));
       t_next = t_next > b1.t ? t_next : up;
     }
-    if (on & (b1.prim >= 0)) trace_tree<STATS>(S, stk, root, ob.first, q, t_next, big, b2, cnt);
+    if (on & (b1.prim >= 0)) trace_tree<STATS>(S, stk, root, root_box, q, t_next, big, b2, cnt);
     float t1 = b1.t, t2 = b2.t;
     t1 = t1 < t_min ? t_min : t1;
     t2 = t2 > t_max ? t_max : t2;
@@ -2732,7 +2733,7 @@ __global__ void __launch_bounds__(64, GENERAL < 1 ? RT_STACK_WAVES : (GENERAL < 
       if (STATS) cnt.rays += go;
       Counters c2;  // (the root test of lanes that do not start a ray is not an event)
       memset(&c2, 0, sizeof(c2));
-      const int first = trav_enter<STATS>(S, S.root_ref, 0, nr, a_t_min, INFINITY, c2);
+      const int first = trav_enter<STATS>(S, S.root_ref, S.root_box, nr, a_t_min, INFINITY, c2);
       if (STATS) cnt.node_tests += go;
       T.r.inv = sel3(go, nr.inv, T.r.inv);
       T.cur = go ? first : T.cur;
@@ -3165,7 +3166,7 @@ __global__ void __launch_bounds__(64, GENERAL < 2 ? 5 : 4) render_pool_kernel(De
       rd = sel3(keeps, rd, f3(1.0f, 1.0f, 1.0f));
       Counters c2;  // (counted where a lane takes the ray)
       memset(&c2, 0, sizeof(c2));
-      const int first = trav_enter<STATS>(S, S.root_ref, 0, make_ray(ro, rd), a_t_min, INFINITY, c2);
+      const int first = trav_enter<STATS>(S, S.root_ref, S.root_box, make_ray(ro, rd), a_t_min, INFINITY, c2);
       if (keeps) {
         rec[0] = (f32x4){ro.x, ro.y, ro.z, 0.0f};
         rec[1] = (f32x4){rd.x, rd.y, rd.z, __int_as_float(first)};
@@ -3922,10 +3923,22 @@ struct TreeBuilder {
   // A ConstantMedium is no leaf of this tree: the render kernel walks the media after the tree (they draw random
   // numbers) and a deterministic query skips them, so a lane that reached one would only fetch its records and leave;
   // the global mist of the final scene, whose box is the whole scene, cost every ray one such visit.
+  // A BvhNode item without a frame change joins its parent's tree when its root box is an ordinary one.  The sub-tree the
+  // flattener writes for a nested HitableList has infinite boxes (every ray tries every item of a list): its object keeps its
+  // own leaf, because the box of that leaf (the list's bounding box, which the reference's parent BvhNode tests) is then the
+  // only box between a ray and the items, and it need not contain them (a sphere of negative radius has an inverted box).
+  static bool joins_parent(const rt_scene* s, int object) {
+    const rt_object& ob = s->objects[object];
+    if (ob.kind != RT_OBJ_BVH || (ob.xform & 3) != 0) return false;
+    const rt_node& root = s->nodes[ob.first];
+    for (int c = 0; c < 3; ++c)
+      if (!std::isfinite(root.bmin[c]) || !std::isfinite(root.bmax[c])) return false;
+    return true;
+  }
   void collect(int idx, std::vector<int>* out, bool media = false) const {
     const rt_node& n = s->nodes[idx];
     if (n.left < 0) {
-      if (n.right == 0 && s->objects[~n.left].kind == RT_OBJ_BVH && (s->objects[~n.left].xform & 3) == 0) collect(s->objects[~n.left].first, out, media);
+      if (n.right == 0 && joins_parent(s, ~n.left)) collect(s->objects[~n.left].first, out, media);
       else if (media || !(n.right == 0 && s->objects[~n.left].kind >= RT_OBJ_MEDIUM)) out->push_back(idx);
       return;
     }
@@ -4202,7 +4215,7 @@ struct TreeBuilder {
   int mirror(int idx) {
     const rt_node& n = s->nodes[idx];
     if (n.left < 0) {
-      if (n.right == 0 && s->objects[~n.left].kind == RT_OBJ_BVH && (s->objects[~n.left].xform & 3) == 0) return mirror(s->objects[~n.left].first);
+      if (n.right == 0 && joins_parent(s, ~n.left)) return mirror(s->objects[~n.left].first);
       if (n.right == 0 && s->objects[~n.left].kind >= RT_OBJ_MEDIUM) return -1;
       LeafRec q;
       for (int c = 0; c < 3; ++c) { q.bmin[c] = n.bmin[c]; q.bmax[c] = n.bmax[c]; }
@@ -4276,7 +4289,7 @@ struct Wide4Builder {
   static void prebuild(const rt_scene* s, TreeBuilder* T, std::vector<int>* roots) {
     roots->assign((size_t)s->n_objects, -1);
     for (int i = 0; i < s->n_objects; ++i)
-      if (s->objects[i].kind == RT_OBJ_BVH && (s->objects[i].xform & 3) != 0) (*roots)[(size_t)i] = T->build_under(s->objects[i].first);
+      if (s->objects[i].kind == RT_OBJ_BVH && !TreeBuilder::joins_parent(s, i)) (*roots)[(size_t)i] = T->build_under(s->objects[i].first);
   }
   int ref_of_leaf(int ref_node) const {
     const rt_node& c = s->nodes[ref_node];
@@ -4295,7 +4308,7 @@ struct Wide4Builder {
       int sub = 0;
       const int sub_root = (*sub_tree_root)[(size_t)~leaf.left];
       const int r = ref_of(sub_root, &sub, 99);
-      (*sub_root_ref)[(size_t)~leaf.left] = r;
+      (*sub_root_ref)[2 * (size_t)~leaf.left] = r;
       if (!(r & BN2_LEAF)) touched.push_back(~leaf.left);
       *need = 4 + sub;  // the world ray (three entries) and the marker that switches the lane back to it
     }
@@ -4309,7 +4322,7 @@ struct Wide4Builder {
       for (int c = 0; c < 4; ++c)
         if (out[i].ref[c] != BN4_EMPTY && !(out[i].ref[c] & BN2_LEAF)) out[i].ref[c] += off;
     for (size_t k = 0; k < part.touched.size(); ++k) {
-      (*sub_root_ref)[(size_t)part.touched[k]] += off;
+      (*sub_root_ref)[2 * (size_t)part.touched[k]] += off;
       touched.push_back(part.touched[k]);
     }
     return part_root + off;
@@ -4830,11 +4843,11 @@ int rt_upload_scene_timed(rt_ctx* ctx, const rt_scene* s, double* upload_ms) {
   Wide4Builder W;
   W.s = s;
   W.T = &TB;
-  W.sub_root_ref_own.assign((size_t)s->n_objects, 0);
+  W.sub_root_ref_own.assign(2 * (size_t)s->n_objects, 0);
   W.sub_root_ref = &W.sub_root_ref_own;
   std::vector<int> sub_tree_root;
   W.sub_tree_root = &sub_tree_root;
-  int root_ref = 0, stack_need = 0;
+  int root_ref = 0, stack_need = 0, world_root_box = 0;
   std::vector<int> box6_index((size_t)s->n_prims, -1);
   std::vector<float> box6_recs;
   if (want_stack) {
@@ -4873,8 +4886,20 @@ int rt_upload_scene_timed(rt_ctx* ctx, const rt_scene* s, double* upload_ms) {
       for (int i = 0; i < s->n_objects; ++i) {
         if (s->objects[i].kind != RT_OBJ_MEDIUM_BVH) continue;
         int sub = 0;
-        W.sub_root_ref_own[(size_t)i] = W.ref_of(medium_root[(size_t)i], &sub);
+        W.sub_root_ref_own[2 * (size_t)i] = W.ref_of(medium_root[(size_t)i], &sub);
         if (sub > stack_need) stack_need = sub;
+      }
+      // The node whose box a walk tests before it takes a tree's root (bvh.rs:198): the given root's, whose box is the
+      // union of the leaves' boxes like the device's own root's; but a tree of ONE leaf has no entry that holds the leaf's
+      // box, and the leaf need not be the given root (a BvhNode of one item inside a list): then the leaf's own node.
+      auto box_node_of = [&](int built_root, int given_root) {
+        const BuildNode& b = TB.nodes[(size_t)built_root];
+        return b.ref_node >= 0 ? b.ref_node : given_root;
+      };
+      world_root_box = box_node_of(world_root, 0);
+      for (int i = 0; i < s->n_objects; ++i) {
+        const int built = s->objects[i].kind == RT_OBJ_MEDIUM_BVH ? medium_root[(size_t)i] : sub_tree_root[(size_t)i];
+        if (built >= 0) W.sub_root_ref_own[2 * (size_t)i + 1] = box_node_of(built, s->objects[i].first);
       }
     };
     lap("six-rect records");
@@ -5061,6 +5086,7 @@ int rt_upload_scene_timed(rt_ctx* ctx, const rt_scene* s, double* upload_ms) {
   d.bnodes4 = (const BNode4*)ctx->d_bnodes4;
   d.root_ref = root_ref;
   d.sub_root_ref = (const int*)ctx->d_sub_root_ref;
+  d.root_box = world_root_box;
   d.box6_index = (const int*)ctx->d_box6_index;
   d.box6_recs = (const float4*)ctx->d_box6_recs;
   d.prim_rank = (const int*)ctx->d_prim_rank;

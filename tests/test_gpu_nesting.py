@@ -222,7 +222,23 @@ def test_sphere_of_negative_radius_in_a_wrapped_list(gpu, orc):
             inner = S.HitableList.new([S.Sphere.new(S.vec3(*c), -float(rng.uniform(1.0, 2.5)), m),
                                        S.Sphere.new(S.vec3(*(c + rng.uniform(-3, 3, 3))), 0.4, m)])
             items.append(S.Translate.new(S.RotateY.new(inner, float(rng.uniform(-60, 60))), S.vec3(*rng.uniform(-1, 1, 3))))
+        # the same inside a list inside a turned list: the inner list's box (too small) is the only box between a ray
+        # and the hollow sphere, and it must stay one (an untransformed nested list is not merged into its parent's tree)
+        for k in range(8):
+            c = rng.uniform(-8, 8, 3)
+            inner = S.HitableList.new([S.Sphere.new(S.vec3(*c), -float(rng.uniform(1.0, 2.5)), m),
+                                       S.Sphere.new(S.vec3(*(c + rng.uniform(-3, 3, 3))), 0.4, m)])
+            items.append(S.RotateY.new(S.HitableList.new([inner, S.Sphere.new(S.vec3(*rng.uniform(-8, 8, 3)), 0.5, m)]), float(rng.uniform(-60, 60))))
+        # and a BvhNode of one hollow sphere inside a turned list: its box is the sphere's inverted one, which no ray passes
+        # (the tree under the list then is a single leaf, whose own box is the one to test on the way in)
+        never = []
+        for k in range(8):
+            c = rng.uniform(-8, 8, 3)
+            items.append(S.RotateY.new(S.HitableList.new([S.BvhNode.new([S.Sphere.new(S.vec3(*c), -2.0, m)])]), float(rng.uniform(-60, 60))))
+            never.append(c)
         flat = sc.flatten(S.HitableList.new(items))
-    prim = _check_trace(gpu, orc, flat, rng, m=30000)
+    prim = _check_trace(gpu, orc, flat, rng, m=40000)
     hollow = [k for k in range(flat.n_prims) if flat.prims[k].f[3] < 0.0]
-    assert len(hollow) == 12 and np.isin(prim, hollow).sum() > 100
+    assert len(hollow) == 28 and np.isin(prim, hollow).sum() > 100
+    unreachable = [k for k in hollow if flat.prims[k].f[3] == -2.0]
+    assert len(unreachable) == 8 and not np.isin(prim, unreachable).any()
