@@ -3968,7 +3968,10 @@ struct TreeBuilder {
   int n_threads = 1;
   std::vector<LeafRec> scratch;  // as long as the leaf array when a range is large enough for a parallel partition
   static const int kBins = 16;
-  static const int kSmall = 8;  // ranges up to this many leaves are split by the exact search
+#ifndef RT_SAH_EXACT_LEAVES
+#define RT_SAH_EXACT_LEAVES 8
+#endif
+  static const int kSmall = RT_SAH_EXACT_LEAVES;  // ranges up to this many leaves are split by the exact search
   struct Bins {
     float blo[3][kBins][3], bhi[3][kBins][3];
     int cnt[3][kBins];
