@@ -185,6 +185,7 @@ def test_keep_tree_option_walks_the_given_interior(gpu, orc):
         flat = sc.flatten(world)
     p = make_params(64, 48, 4, seed=3)
     cam = S.Camera.new(S.vec3(0.0, 4.0, 30.0), S.vec3(0.0, 0.0, 0.0), S.vec3(0.0, 1.0, 0.0), 40.0, 64.0 / 48.0, 0.0, 10.0)
+    gpu.set_option(RT_OPT_KEEP_TREE, 0)  # (whatever the environment preset)
     gpu.upload_scene(flat)
     _, st_own = gpu.render(cam, p, want_stats=True)
     gpu.set_option(RT_OPT_KEEP_TREE, 1)
