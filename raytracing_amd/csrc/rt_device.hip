@@ -3894,6 +3894,27 @@ int build_bnodes(const rt_scene* s, int idx, std::vector<BNode>* out, std::vecto
   return RT_OK;
 }
 
+// build_bnodes for a large tree without sub-trees: the leaves under every node are known (count_leaves), so the rank at which
+// a subtree starts is known before its left sibling has been walked, and the halves of the top levels go to threads.
+int build_bnodes_by_threads(const rt_scene* s, const std::vector<int>& leaves, int idx, std::vector<BNode>* out, std::vector<int>* prim_rank,
+                            int rank_start, int depth) {
+  const rt_node& n = s->nodes[idx];
+  if (n.left < 0 || depth >= 4 || leaves[(size_t)idx] < (1 << 15)) {
+    int rank = rank_start;
+    return build_bnodes(s, idx, out, prim_rank, &rank);
+  }
+  BNode& b = (*out)[(size_t)idx];
+  for (int c = 0; c < 3; ++c) { b.bmin[c] = n.bmin[c]; b.bmax[c] = n.bmax[c]; }
+  b.left = n.left;
+  b.right = n.right;
+  if (n.left > BN_INDEX_MASK || n.right > BN_INDEX_MASK) return rt::set_error(RT_ERR_UNSUPPORTED, "too many nodes");
+  int rc_left = RT_OK;
+  std::thread left_half([&]() { rc_left = build_bnodes_by_threads(s, leaves, n.left, out, prim_rank, rank_start, depth + 1); });
+  const int rc_right = build_bnodes_by_threads(s, leaves, n.right, out, prim_rank, rank_start + leaves[(size_t)n.left], depth + 1);
+  left_half.join();
+  return rc_left != RT_OK ? rc_left : rc_right;
+}
+
 // The tree the stack traversal walks.  Its LEAVES are the reference tree's leaves with the reference's boxes, and the
 // order that decides an exact tie is the reference's depth-first order (prim_rank); its interior structure is the
 // device's own.  That changes no result: BvhNode::hit (bvh.rs:197-228) returns the nearest hit among the leaves that
@@ -4947,8 +4968,21 @@ int rt_upload_scene_timed(rt_ctx* ctx, const rt_scene* s, double* upload_ms) {
   if (stack_mode) {
     bnodes.assign((size_t)s->n_nodes, BNode());
     int rank = 0;
-    rc = build_bnodes(s, 0, &bnodes, &prim_rank, &rank);
+    bool sub_trees = false;
+    for (int i = 0; i < s->n_objects; ++i) sub_trees |= s->objects[i].kind == RT_OBJ_BVH || s->objects[i].kind == RT_OBJ_MEDIUM_BVH;
+    if (!sub_trees && s->n_nodes >= (1 << 17)) rc = build_bnodes_by_threads(s, B.leaves, 0, &bnodes, &prim_rank, 0, 0);
+    else rc = build_bnodes(s, 0, &bnodes, &prim_rank, &rank);
     if (rc != RT_OK) return rc;
+    if (verbose && !sub_trees && s->n_nodes >= (1 << 17)) {
+      // (RT_VERBOSE: the ranks the threads made against the ranks of the plain walk)
+      std::vector<BNode> check_nodes((size_t)s->n_nodes, BNode());
+      std::vector<int> check_rank((size_t)s->n_prims, 0);
+      int r2 = 0;
+      (void)build_bnodes(s, 0, &check_nodes, &check_rank, &r2);
+      size_t differ = 0;
+      for (size_t i = 0; i < check_rank.size(); ++i) differ += check_rank[i] != prim_rank[i];
+      std::fprintf(stderr, "rt_upload_scene: ranks made by threads: %zu of %zu differ from the plain walk's\n", differ, check_rank.size());
+    }
     // (a medium is no leaf of the device's world tree, so build_bnodes, which follows the given one, has met every medium's sub-tree too)
     for (size_t i = 0; i < B.out.size();) {
       const int slots = B.out[i].kind == K_INTERIOR ? 1 : B.out[i].skip - (int)i;

@@ -4,7 +4,8 @@ import os
 import sys
 import time
 
-os.environ["RT_VERBOSE"] = "1"
+if "quiet" not in sys.argv:
+    os.environ["RT_VERBOSE"] = "1"  # the library's own breakdown (and, for large trees, its check of the ranks made by threads)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from raytracing_amd import Renderer, Scene  # noqa: E402
@@ -15,7 +16,7 @@ class A(object):
     spheres = 1 << 20
 
 
-name = sys.argv[1] if len(sys.argv) > 1 else "stress"
+name = sys.argv[1] if len(sys.argv) > 1 and sys.argv[1] != "quiet" else "stress"
 t0 = time.perf_counter()
 with Scene(0x5EED0000) as sc:
     cam, world, light, sky = build(name, 16.0 / 9.0, A)
@@ -24,7 +25,7 @@ with Scene(0x5EED0000) as sc:
     flat = sc.flatten(world)
 print("scene construction and flattening (host classes): %.1f ms, %d nodes, %d primitives" % ((time.perf_counter() - t0) * 1e3, flat.n_nodes, flat.n_prims))
 r = Renderer(0)
-for k in range(2):
+for k in range(5):
     r.upload_scene(flat)
     print("rt_upload_scene: host build %.1f ms, device copies %.1f ms" % r.upload_ms)
 r.close()
