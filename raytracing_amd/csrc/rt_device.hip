@@ -47,6 +47,7 @@
 #include <cstring>
 #include <string>
 #include <memory>
+#include <system_error>
 #include <thread>
 #include <vector>
 
@@ -3697,6 +3698,17 @@ float round_up(double v) {
   return std::nextafter(std::nextafter(f, INFINITY), INFINITY);
 }
 
+// `work` on a thread of its own if one can be had; where the system refuses a thread (std::system_error) the work is done
+// here and now, and the returned thread is not joinable.  The build's threads only ever make it faster.
+template <class F> std::thread try_thread(F work) {
+  try {
+    return std::thread(work);
+  } catch (const std::system_error&) {
+    work();
+    return std::thread();
+  }
+}
+
 // How high the primitives of prims[first, first+count) reach, in their own frame.
 double geometry_top(const rt_scene* s, int first, int count) {
   double top = -INFINITY;
@@ -3723,9 +3735,9 @@ float compute_y_top(const rt_scene* s, int idx, int depth, std::vector<float>* y
     if (depth < 4 && s->n_nodes >= (1 << 16)) {
       // (the tree has been checked by now: no node is reached twice, so the two halves write different elements)
       float top_left = -INFINITY;
-      std::thread left_half([&]() { top_left = compute_y_top(s, n.left, depth + 1, y_top); });
+      std::thread left_half = try_thread([&]() { top_left = compute_y_top(s, n.left, depth + 1, y_top); });
       top = std::max(top, compute_y_top(s, n.right, depth + 1, y_top));
-      left_half.join();
+      if (left_half.joinable()) left_half.join();
       top = std::max(top, top_left);
     } else {
       top = std::max(top, compute_y_top(s, n.left, depth + 1, y_top));
@@ -3909,9 +3921,9 @@ int build_bnodes_by_threads(const rt_scene* s, const std::vector<int>& leaves, i
   b.right = n.right;
   if (n.left > BN_INDEX_MASK || n.right > BN_INDEX_MASK) return rt::set_error(RT_ERR_UNSUPPORTED, "too many nodes");
   int rc_left = RT_OK;
-  std::thread left_half([&]() { rc_left = build_bnodes_by_threads(s, leaves, n.left, out, prim_rank, rank_start, depth + 1); });
+  std::thread left_half = try_thread([&]() { rc_left = build_bnodes_by_threads(s, leaves, n.left, out, prim_rank, rank_start, depth + 1); });
   const int rc_right = build_bnodes_by_threads(s, leaves, n.right, out, prim_rank, rank_start + leaves[(size_t)n.left], depth + 1);
-  left_half.join();
+  if (left_half.joinable()) left_half.join();
   return rc_left != RT_OK ? rc_left : rc_right;
 }
 
@@ -4003,9 +4015,10 @@ struct TreeBuilder {
     const long long n = end - begin;
     if (n_chunks <= 1) { fn(0, begin, end); return; }
     std::vector<std::thread> th;
-    for (int t = 1; t < n_chunks; ++t) th.emplace_back([=, &fn]() { fn(t, begin + (int)(n * t / n_chunks), begin + (int)(n * (t + 1) / n_chunks)); });
+    for (int t = 1; t < n_chunks; ++t) th.push_back(try_thread([=, &fn]() { fn(t, begin + (int)(n * t / n_chunks), begin + (int)(n * (t + 1) / n_chunks)); }));
     fn(0, begin, begin + (int)(n / n_chunks));
-    for (size_t t = 0; t < th.size(); ++t) th[t].join();
+    for (size_t t = 0; t < th.size(); ++t)
+      if (th[t].joinable()) th[t].join();
   }
   // Builds the subtree over leaves[begin, end) (reordered in place) into nodes[base, base + 2 (end - begin) - 1): the
   // left subtree's nodes, the right subtree's, then the root, which is what it returns.  A subtree's slots are known
@@ -4209,9 +4222,9 @@ struct TreeBuilder {
     int l = 0, r = 0;
     const size_t right_base = base + 2 * (size_t)(mid - begin) - 1;
     if (end - begin >= 32768 && depth < 6) {
-      std::thread left_half([&]() { l = build(leaves, begin, mid, base, depth + 1); });
+      std::thread left_half = try_thread([&]() { l = build(leaves, begin, mid, base, depth + 1); });
       r = build(leaves, mid, end, right_base, depth + 1);
-      left_half.join();
+      if (left_half.joinable()) left_half.join();
     } else {
       l = build(leaves, begin, mid, base, depth + 1);
       r = build(leaves, mid, end, right_base, depth + 1);
@@ -4394,7 +4407,7 @@ struct Wide4Builder {
           q->w.s = s; q->w.T = T; q->w.sub_root_ref = sub_root_ref; q->w.sub_tree_root = sub_tree_root; q->w.box6_index = box6_index;
           q->w.out.reserve((size_t)k.n_leaves * 5 / 8);  // (about half as many entries as leaves; no more than one per interior node)
           const int kid = kids[c];
-          q->th = std::thread([q, kid, depth]() { q->root = q->w.build(kid, &q->need, depth + 1); });
+          q->th = try_thread([q, kid, depth]() { q->root = q->w.build(kid, &q->need, depth + 1); });
           continue;
         }
         int sub = 0;
@@ -4408,7 +4421,7 @@ struct Wide4Builder {
       }
     }
     for (int c = 0; c < 4; ++c)
-      if (parts[c]) parts[c]->th.join();
+      if (parts[c] && parts[c]->th.joinable()) parts[c]->th.join();
     for (int c = 0; c < 4; ++c) {
       if (!parts[c]) continue;
       b.ref[c] = adopt(parts[c]->w, parts[c]->root);
