@@ -1843,8 +1843,19 @@ struct Shaded {
 };
 // Every lane runs it; dead lanes and misses work on primitive 0 with their results masked by the caller.  `w` is the
 // Philox call of this vertex.
+// The 64-byte record of the primitive a lane hit (primitive 0 for a lane without a hit), as four 16-byte loads.  A caller
+// with other work to do before it shades (the media, the vertex's Philox call) issues these first.
+struct PrimRec {
+  float4 q0, q1, q2, q3;
+};
+__device__ __forceinline__ PrimRec load_prim_rec(const float4* dprim_tab, bool alive, int prim) {
+  const float4* src = (const float4*)((const char*)dprim_tab + ((unsigned)((alive & (prim >= 0)) ? prim : 0) << 6));
+  PrimRec r;
+  r.q0 = src[0]; r.q1 = src[1]; r.q2 = src[2]; r.q3 = src[3];
+  return r;
+}
 template <bool STATS, int GENERAL>
-__device__ __forceinline__ Shaded shade_vertex(const DevScene& S, const float4* dprim_tab, bool alive, const Hit& h, const RayF& ray, F3 thr,
+__device__ __forceinline__ Shaded shade_vertex(const DevScene& S, const PrimRec& rec, bool alive, const Hit& h, const RayF& ray, F3 thr,
                                                int depth, const U4& w, int a_max_depth, int a_sky, unsigned pixel_id, unsigned sample,
                                                unsigned key0, unsigned key1, Counters& cnt) {
   Shaded out;
@@ -1853,8 +1864,7 @@ __device__ __forceinline__ Shaded shade_vertex(const DevScene& S, const float4* 
   const bool hit = alive & (h.prim >= 0);
   DevPrim q;
   {
-    const float4* src = (const float4*)((const char*)dprim_tab + ((unsigned)(hit ? h.prim : 0) << 6));
-    const float4 q0 = src[0], q1 = src[1], q2 = src[2], q3 = src[3];
+    const float4 q0 = rec.q0, q1 = rec.q1, q2 = rec.q2, q3 = rec.q3;
     __builtin_memcpy((char*)&q, &q0, 16);
     __builtin_memcpy((char*)&q + 16, &q1, 16);
     __builtin_memcpy((char*)&q + 32, &q2, 16);
@@ -2303,7 +2313,7 @@ __global__ void __launch_bounds__(64, (TRAV == TRAV_STACK && GENERAL < 2) ? 6 : 
     const Hit h = trace_scan<STATS, TRAV, GENERAL != 0>(S, stk, box_tab, alive, ray, a_t_min, INFINITY, rng, cnt);
 
     // ---- color(), main.rs:165-209, one vertex ----
-    const Shaded sh = shade_vertex<STATS, GENERAL>(S, dprim_tab, alive, h, ray, thr, depth, w, a_max_depth, a_sky, pixel_id, sample, key0, key1, cnt);
+    const Shaded sh = shade_vertex<STATS, GENERAL>(S, load_prim_rec(dprim_tab, alive, h.prim), alive, h, ray, thr, depth, w, a_max_depth, a_sky, pixel_id, sample, key0, key1, cnt);
     const F3 radiance = sh.radiance, dir = sh.dir, thr_next = sh.thr_next;
     const bool scattered = sh.scattered, textured = sh.textured, emits = sh.emits;
     // A zero or NaN weight fixes the sample's value (0 after de_nan) whatever the
@@ -2525,6 +2535,13 @@ __global__ void __launch_bounds__(64, GENERAL < 1 ? RT_STACK_WAVES : (GENERAL < 
     const bool act = ready & alive;  // lanes whose traversal has ended: shade that vertex
     RT_COUNT(8, 1); RT_COUNT(9, __popcll(__ballot(act)));
     if (__ballot(act) != 0ull) {
+      // The record of the primitive the walk found is asked for now and used after the media and the vertex's Philox call,
+      // which hide its latency; the few lanes whose hit a medium replaces ask again.
+      // (The builds with textures are at their register limit: they ask where they always did, just before shading;
+      // asking early cost the final scene 1.2 % and gave the Book-1 scene 1.4 %.)
+      PrimRec hit_rec;
+      if (GENERAL < 2) hit_rec = load_prim_rec(dprim_tab, act, T.best.prim);
+      const int walk_prim = T.best.prim;
       // what is left of world.hit: the ConstantMedium nodes (they draw random numbers)
       if (GENERAL != 0 && S.n_media_sph > 0) {
         const PathRng rng = {pixel_id, sample, (unsigned)depth, key0, key1};
@@ -2539,7 +2556,15 @@ __global__ void __launch_bounds__(64, GENERAL < 1 ? RT_STACK_WAVES : (GENERAL < 
       }
       RT_STAMP(1);  // media
       const U4 w = philox4x32_10(pixel_id, sample, (unsigned)depth, 0u, key0, key1);
-      const Shaded sh = shade_vertex<STATS, GENERAL>(S, dprim_tab, act, T.best, RT_WORLD_RAY(), thr, depth, w, a_max_depth, a_sky, pixel_id, sample, key0, key1, cnt);
+      if (GENERAL >= 2) hit_rec = load_prim_rec(dprim_tab, act, T.best.prim);
+      if (GENERAL == 1) {
+        const bool moved = act & (T.best.prim != walk_prim);
+        if (__ballot(moved) != 0ull) {
+          const PrimRec again = load_prim_rec(dprim_tab, act, T.best.prim);
+          if (moved) hit_rec = again;
+        }
+      }
+      const Shaded sh = shade_vertex<STATS, GENERAL>(S, hit_rec, act, T.best, RT_WORLD_RAY(), thr, depth, w, a_max_depth, a_sky, pixel_id, sample, key0, key1, cnt);
       RT_STAMP(2);  // philox + shade
       const bool go_on = act & sh.scattered & ((sh.thr_next.x > 0.0f) | (sh.thr_next.y > 0.0f) | (sh.thr_next.z > 0.0f));
       const bool done = act & !go_on;
@@ -3063,7 +3088,7 @@ __global__ void __launch_bounds__(64, GENERAL < 2 ? 5 : 4) render_pool_kernel(De
       }
       RT_STAMP(1);  // media
       const U4 w = philox4x32_10(pixel_id, sample, (unsigned)depth, 0u, key0, key1);
-      const Shaded sh = shade_vertex<STATS, GENERAL>(S, dprim_tab, act, h, ray, thr, depth, w, a_max_depth, a_sky, pixel_id, sample, key0, key1, cnt);
+      const Shaded sh = shade_vertex<STATS, GENERAL>(S, load_prim_rec(dprim_tab, act, h.prim), act, h, ray, thr, depth, w, a_max_depth, a_sky, pixel_id, sample, key0, key1, cnt);
       RT_STAMP(2);  // philox + shade
       const bool go_on = act & sh.scattered & ((sh.thr_next.x > 0.0f) | (sh.thr_next.y > 0.0f) | (sh.thr_next.z > 0.0f));
       const bool done = act & !go_on;
